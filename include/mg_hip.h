@@ -1,0 +1,175 @@
+/*
+ * mg_hip.h -- C ABI of the MI355X-native multigrid Poisson engine (libmgpoisson.so).
+ *
+ * Drop-in boundary for the V/W-cycle hot path of cindytsai/multigrid_poisson_solver.
+ * The reference has no FFI layer: its "interface" is the set of free functions its
+ * driver calls (src/MG_solver_CPU.cpp:16-30, GPU twins src/MG_solver_GPU.cu:27-41).
+ * Every operator below keeps the reference's argument list and meaning; the one
+ * change is that U/F/D are DEVICE-resident fp64 arrays (row-major N x N,
+ * index = col + N*row, boundary included -- src/MG_solver_CPU.cpp:484) obtained from
+ * mg_alloc(), because re-uploading per call (src/MG_solver_GPU.cu:1159-1282) can never
+ * approach the HBM roofline.  include/mg_dropin.hpp maps the reference's C++ names
+ * onto these symbols so the reference's own main() compiles against this library
+ * (see INTEGRATION.md).
+ *
+ * Conventions kept from the reference: caller owns all arrays,
+ * callee may use internal scratch, results are visible when the call returns for every
+ * entry point that hands a value back to the host, single caller thread, int sizes.
+ * Errors: the reference printf+exit(1)s; here a failed call prints to stderr, records
+ * a code readable through mg_last_error() and (default) aborts the process with
+ * exit(1) -- mg_set_abort_on_error(0) turns the abort off for embedding in tests.
+ *
+ * All calls are enqueued on ONE HIP stream (mg_set_stream / mg_get_stream).
+ */
+#ifndef MG_HIP_H
+#define MG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* lifecycle                                                                  */
+/* ------------------------------------------------------------------------- */
+/* replaces cudaSetDevice(0), src/MG_solver_GPU.cu:58-62.  Returns 0 on success. */
+int         mg_init(int device);
+void        mg_finalize(void);
+/* use the caller's hipStream_t (NULL = the engine's own stream) */
+void        mg_set_stream(void *hip_stream);
+void       *mg_get_stream(void);
+void        mg_sync(void);
+int         mg_last_error(void);
+const char *mg_last_error_string(void);
+void        mg_clear_error(void);
+void        mg_set_abort_on_error(int on);
+/* "stream" (default: temporally blocked wave-streaming kernels) or "simple"
+ * (one launch per sweep, one thread per point); also read from env MG_SMOOTHER. */
+int         mg_set_smoother(const char *name);
+const char *mg_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* memory: replaces malloc/free of ListNode (src/linkedlist.cpp:9-11,21-23,48-50)
+ * and of tempU (src/MG_solver_CPU.cpp:353,371).  Served from a caching pool so the
+ * timed window contains no hipMalloc.                                         */
+/* ------------------------------------------------------------------------- */
+double *mg_alloc(size_t n_doubles);
+void    mg_free(double *dev);
+void    mg_pool_trim(void);
+size_t  mg_pool_bytes(void);
+void    mg_upload(double *dev, const double *host, size_t n_doubles);   /* synchronous */
+void    mg_download(double *host, const double *dev, size_t n_doubles); /* synchronous */
+void    mg_copy(double *dst_dev, const double *src_dev, size_t n_doubles);
+/* memset(U, 0, N*N*8): src/MG_solver_CPU.cpp:213,256 */
+void    mg_fill_zero(double *dev, size_t n_doubles);
+/* D[i] = -D[i] for all N*N entries: the driver's own loop, src/MG_solver_CPU.cpp:277-280 */
+void    mg_negate(int N, double *D);
+
+/* ------------------------------------------------------------------------- */
+/* problem definition: src/MG_solver_CPU.cpp:468-548                          */
+/* ------------------------------------------------------------------------- */
+void mg_getSource(int N, double L, double *F, double min_x, double min_y);
+void mg_getAnalytic(int N, double L, double *U, double min_x, double min_y);
+/* sum|analytic - U| / (N*N): src/MG_solver_CPU.cpp:434-445; result to *error_host */
+void mg_analyticError(int N, double L, const double *U, double min_x, double min_y, double *error_host);
+
+/* ------------------------------------------------------------------------- */
+/* the six operators: src/MG_solver_CPU.cpp:23-28 (same order, same arguments)  */
+/* ------------------------------------------------------------------------- */
+/* :554-564 */
+void mg_getResidual(int N, double L, double *U, double *F, double *D);
+/* :566-571 */
+void mg_doGridAddition(int N, double *U1, double *U2);
+/* :573-625.  error is a HOST pointer (as in the reference, where it points into the
+ * ListNode); the call returns after the value is written.  NULL = not wanted. */
+void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *error);
+/* :627-638, option 1 = red-black Gauss-Seidel :952-1066.  option 0 (dense inverse) is
+ * refused with the message of src/MG_solver_GPU.cu:1286-1289. */
+void mg_doExactSolver(int N, double L, double *U, double *F, double target_error, int option);
+/* :640-680 */
+void mg_doRestriction(int N, double *U_f, int M, double *U_c);
+/* :682-724 */
+void mg_doProlongation(int N, double *U_c, int M, double *U_f);
+
+/* ------------------------------------------------------------------------- */
+/* asynchronous / fused forms used by the engine's own driver                 */
+/* ------------------------------------------------------------------------- */
+/* step Jacobi sweeps from U_in into U_out (U_out != U_in; U_in is clobbered as
+ * scratch when more than one launch is needed).  U_in == NULL means "U is all zero"
+ * (the driver's memset of src/MG_solver_CPU.cpp:256 folded into the first sweep).
+ * error_dev (device pointer or NULL) receives doSmoothing's error; D_out (device
+ * pointer or NULL) receives getResidual(U_out) times d_sign (+1 or -1: the driver's
+ * sign flip :277-280 folded in). */
+void mg_smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step,
+                  double *error_dev, double *D_out, int d_sign);
+/* U_f_out = U_f_in + doProlongation(N, U_c, M) in one pass (:354 + :368) */
+void mg_prolongAdd(int N, const double *U_c, int M, const double *U_f_in, double *U_f_out);
+/* doRestriction(N, sign*U_f, M, U_c) */
+void mg_restrict_signed(int N, const double *U_f, int M, double *U_c, int sign);
+/* number of Gauss-Seidel iterations the last mg_doExactSolver call ran (synchronises) */
+int  mg_lastExactSolverIterations(void);
+
+/* ------------------------------------------------------------------------- */
+/* host-side index tables (exact reference expressions, fp64 on the host)      */
+/* ------------------------------------------------------------------------- */
+/* doRestriction :661-666: lo[i] = (int)floor(i*h_c/h_f), w[i] = fmod(i*h_c,h_f)/h_f */
+void mg_restriction_table(int N, int M, int *lo, double *w);
+/* doProlongation :697-718: owner of fine index k along rows (axis 0) or columns
+ * (axis 1) and the two 1-D weights (c_hi - f, f - c_lo) the kernel multiplies with */
+void mg_prolongation_table(int N, int M, int axis, int *owner, double *w_hi, double *w_lo);
+
+/* ------------------------------------------------------------------------- */
+/* synthetic inputs and checksums (benchmark + full-size parity tests)         */
+/* ------------------------------------------------------------------------- */
+/* dst[i] = uniform[0,1) from a counter-based 64-bit hash of (i + seed); the same
+ * recipe as tests/_synth.py:hash_uniform */
+void mg_fill_uniform(double *dst, size_t n_doubles, uint64_t seed);
+/* out[0] = sum of bit patterns, out[1] = sum of bit patterns * (2*i+1), mod 2^64,
+ * with -0.0 canonicalised to +0.0 (tests/_synth.py:checksum); synchronous */
+void mg_checksum(const double *src, size_t n_doubles, uint64_t out[2]);
+
+/* ------------------------------------------------------------------------- */
+/* cycle-file driver: main() of src/MG_solver_CPU.cpp:36-462                   */
+/* ------------------------------------------------------------------------- */
+typedef struct mg_node_record {
+    int    node;   /* -1, 0, 1 */
+    int    N;
+    int    steps;
+    double error;
+} mg_node_record;
+
+typedef struct mg_cycle_result {
+    int     status;        /* 0 ok */
+    int     N;             /* finest grid */
+    double *U_dev;         /* final solution (device, owned by the plan) */
+    double  mg_error;      /* :434-445 */
+    double  time_ms;       /* host wall clock of the reference's window :156..:429, synchronised */
+    double  device_ms;     /* hipEvent time of the same window */
+    int     n_records;
+    const mg_node_record *records; /* owned by the plan, valid until the next execute */
+    const char *report;    /* the reference's printed report (owned by the plan) */
+} mg_cycle_result;
+
+typedef struct mg_cycle_plan mg_cycle_plan;
+
+#define MG_CYCLE_FUSED   1 /* use the fused operators (default driver mode) */
+#define MG_CYCLE_GRAPH   2 /* capture the node program into a hipGraph and replay it */
+#define MG_CYCLE_REPORT  4 /* build the printed report text */
+
+/* parse a cycle structure file (README.md:43-128); allocates the finest level and
+ * evaluates getSource on it (:149-153, outside the timed window) */
+mg_cycle_plan *mg_cycle_load(const char *path, int flags);
+/* one run of the reference's timed window from the state right after getSource */
+int            mg_cycle_execute(mg_cycle_plan *plan, mg_cycle_result *out);
+void           mg_cycle_destroy(mg_cycle_plan *plan);
+/* the whole reference program: load, execute, print report, write Sol_HIP_<file> CSV */
+int            mg_cycle_main(int argc, char **argv);
+/* CSV writer of src/MG_solver_CPU.cpp:735-754 on a device array */
+int            mg_print2File(int N, const double *U_dev, const char *file_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_HIP_H */

@@ -1,0 +1,388 @@
+"""multigrid_poisson_solver_amd -- Python harness over the C ABI of libmgpoisson.so.
+
+The product is the HIP library (csrc/, built by build.py) behind include/mg_hip.h; this
+module only binds it with ctypes for the tests and the benchmark.  It mirrors the
+reference's operator interface (src/MG_solver_CPU.cpp:23-28: getResidual,
+doGridAddition, doSmoothing, doExactSolver, doRestriction, doProlongation) on
+device-resident arrays.  There is no CPU fallback: importing works anywhere, but the
+first call raises if the library or a HIP device is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmgpoisson.so")
+EXE_PATH = os.path.join(_PKG, "bin", "MG_HIP")
+
+MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT = 1, 2, 4
+
+
+class MGError(RuntimeError):
+    pass
+
+
+class NodeRecord(C.Structure):
+    _fields_ = [("node", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("error", C.c_double)]
+
+
+class CycleResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("N", C.c_int), ("U_dev", C.c_void_p), ("mg_error", C.c_double),
+                ("time_ms", C.c_double), ("device_ms", C.c_double), ("n_records", C.c_int),
+                ("records", C.POINTER(NodeRecord)), ("report", C.c_char_p)]
+
+
+_vp, _i, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64
+_dptr = C.POINTER(C.c_double)
+
+# every symbol include/mg_hip.h declares: name -> (restype, argtypes)
+ABI = {
+    "mg_init": (_i, [_i]), "mg_finalize": (None, []), "mg_set_stream": (None, [_vp]),
+    "mg_get_stream": (_vp, []), "mg_sync": (None, []), "mg_last_error": (_i, []),
+    "mg_last_error_string": (C.c_char_p, []), "mg_clear_error": (None, []),
+    "mg_set_abort_on_error": (None, [_i]), "mg_set_smoother": (_i, [C.c_char_p]),
+    "mg_version": (C.c_char_p, []),
+    "mg_alloc": (_vp, [_sz]), "mg_free": (None, [_vp]), "mg_pool_trim": (None, []),
+    "mg_pool_bytes": (_sz, []), "mg_upload": (None, [_vp, _vp, _sz]), "mg_download": (None, [_vp, _vp, _sz]),
+    "mg_copy": (None, [_vp, _vp, _sz]), "mg_fill_zero": (None, [_vp, _sz]), "mg_negate": (None, [_i, _vp]),
+    "mg_getSource": (None, [_i, _d, _vp, _d, _d]), "mg_getAnalytic": (None, [_i, _d, _vp, _d, _d]),
+    "mg_analyticError": (None, [_i, _d, _vp, _d, _d, _dptr]),
+    "mg_getResidual": (None, [_i, _d, _vp, _vp, _vp]), "mg_doGridAddition": (None, [_i, _vp, _vp]),
+    "mg_doSmoothing": (None, [_i, _d, _vp, _vp, _i, _dptr]),
+    "mg_doExactSolver": (None, [_i, _d, _vp, _vp, _d, _i]),
+    "mg_doRestriction": (None, [_i, _vp, _i, _vp]), "mg_doProlongation": (None, [_i, _vp, _i, _vp]),
+    "mg_smooth_pp": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i]),
+    "mg_prolongAdd": (None, [_i, _vp, _i, _vp, _vp]), "mg_restrict_signed": (None, [_i, _vp, _i, _vp, _i]),
+    "mg_lastExactSolverIterations": (_i, []),
+    "mg_restriction_table": (None, [_i, _i, _vp, _vp]),
+    "mg_prolongation_table": (None, [_i, _i, _i, _vp, _vp, _vp]),
+    "mg_fill_uniform": (None, [_vp, _sz, _u64]), "mg_checksum": (None, [_vp, _sz, C.POINTER(_u64)]),
+    "mg_cycle_load": (_vp, [C.c_char_p, _i]), "mg_cycle_execute": (_i, [_vp, C.POINTER(CycleResult)]),
+    "mg_cycle_destroy": (None, [_vp]), "mg_cycle_main": (_i, [_i, C.POINTER(C.c_char_p)]),
+    "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libmgpoisson.so and type every exported symbol.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MGError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    missing = []
+    for name, (res, args) in ABI.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype, fn.argtypes = res, args
+    if missing:
+        raise MGError(f"{path} does not export: {missing}")
+    _lib = lib
+    return lib
+
+
+def _check():
+    code = _lib.mg_last_error()
+    if code:
+        msg = _lib.mg_last_error_string().decode()
+        _lib.mg_clear_error()
+        raise MGError(f"[{code}] {msg}")
+
+
+_initialised = False
+
+
+def init(device=0):
+    global _initialised
+    lib = load_library()
+    lib.mg_set_abort_on_error(0)
+    if lib.mg_init(int(device)) != 0:
+        code = lib.mg_last_error()
+        msg = lib.mg_last_error_string().decode()
+        lib.mg_clear_error()
+        raise MGError(f"mg_init({device}) failed [{code}]: {msg}")
+    _initialised = True
+    return lib
+
+
+def lib():
+    if not _initialised:
+        init(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MG_DEVICE") is None
+             else int(os.environ["MG_DEVICE"]))
+    return _lib
+
+
+def finalize():
+    global _initialised
+    if _initialised:
+        _lib.mg_finalize()
+        _initialised = False
+
+
+def sync():
+    lib().mg_sync()
+    _check()
+
+
+def set_smoother(name):
+    lib().mg_set_smoother(name.encode())
+    _check()
+
+
+class DeviceGrid:
+    """A device-resident fp64 array obtained from mg_alloc (the engine's replacement for
+    the malloc'ed U/F/D of src/linkedlist.cpp:9-11)."""
+
+    def __init__(self, shape):
+        if isinstance(shape, int):
+            shape = (shape, shape)
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(np.prod(self.shape))
+        self.ptr = lib().mg_alloc(self.size)
+        _check()
+        if not self.ptr:
+            raise MGError("mg_alloc returned NULL")
+
+    @property
+    def N(self):
+        return self.shape[0]
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        g = cls(a.shape)
+        _lib.mg_upload(g.ptr, a.ctypes.data, a.size)
+        _check()
+        return g
+
+    @classmethod
+    def zeros(cls, shape):
+        g = cls(shape)
+        _lib.mg_fill_zero(g.ptr, g.size)
+        return g
+
+    @classmethod
+    def uniform(cls, shape, seed):
+        g = cls(shape)
+        _lib.mg_fill_uniform(g.ptr, g.size, seed)
+        return g
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _lib.mg_download(out.ctypes.data, self.ptr, self.size)
+        _check()
+        return out
+
+    def copy(self):
+        g = DeviceGrid(self.shape)
+        _lib.mg_copy(g.ptr, self.ptr, self.size)
+        return g
+
+    def checksum(self):
+        out = (C.c_uint64 * 2)()
+        _lib.mg_checksum(self.ptr, self.size, out)
+        _check()
+        return int(out[0]), int(out[1])
+
+    def free(self):
+        if self.ptr and _initialised:
+            _lib.mg_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------
+# the reference's operator surface (src/MG_solver_CPU.cpp:23-28) on DeviceGrid
+# ---------------------------------------------------------------------------------
+def getSource(N, L=1.0, min_x=0.0, min_y=0.0):
+    F = DeviceGrid(N)
+    _lib.mg_getSource(N, L, F.ptr, min_x, min_y)
+    _check()
+    return F
+
+
+def getAnalytic(N, L=1.0, min_x=0.0, min_y=0.0):
+    U = DeviceGrid(N)
+    _lib.mg_getAnalytic(N, L, U.ptr, min_x, min_y)
+    _check()
+    return U
+
+
+def analyticError(N, L, U, min_x=0.0, min_y=0.0):
+    e = C.c_double()
+    lib().mg_analyticError(N, L, U.ptr, min_x, min_y, C.byref(e))
+    _check()
+    return e.value
+
+
+def getResidual(N, L, U, F, D):
+    lib().mg_getResidual(N, L, U.ptr, F.ptr, D.ptr)
+    _check()
+
+
+def doGridAddition(N, U1, U2):
+    lib().mg_doGridAddition(N, U1.ptr, U2.ptr)
+    _check()
+
+
+def doSmoothing(N, L, U, F, step, want_error=True):
+    """In place, like the reference; returns the error scalar (host double)."""
+    e = C.c_double()
+    lib().mg_doSmoothing(N, L, U.ptr, F.ptr, step, C.byref(e) if want_error else None)
+    _check()
+    return e.value if want_error else None
+
+
+def doExactSolver(N, L, U, F, target_error, option=1):
+    lib().mg_doExactSolver(N, L, U.ptr, F.ptr, target_error, option)
+    _check()
+
+
+def lastExactSolverIterations():
+    n = lib().mg_lastExactSolverIterations()
+    _check()
+    return n
+
+
+def doRestriction(N, U_f, M, U_c):
+    lib().mg_doRestriction(N, U_f.ptr, M, U_c.ptr)
+    _check()
+
+
+def doProlongation(N, U_c, M, U_f):
+    lib().mg_doProlongation(N, U_c.ptr, M, U_f.ptr)
+    _check()
+
+
+def negate(N, D):
+    lib().mg_negate(N, D.ptr)
+    _check()
+
+
+def smooth_pp(N, L, U_in, U_out, F, step, want_error=False, D_out=None, d_sign=1):
+    """Out-of-place fused form (mg_smooth_pp).  U_in None = all-zero start."""
+    err = DeviceGrid((1,)) if want_error else None
+    lib().mg_smooth_pp(N, L, U_in.ptr if U_in is not None else None, U_out.ptr, F.ptr, step,
+                       err.ptr if err else None, D_out.ptr if D_out is not None else None, d_sign)
+    _check()
+    if want_error:
+        v = float(err.to_host()[0])
+        err.free()
+        return v
+    return None
+
+
+def prolongAdd(N, U_c, M, U_f_in, U_f_out):
+    lib().mg_prolongAdd(N, U_c.ptr, M, U_f_in.ptr, U_f_out.ptr)
+    _check()
+
+
+def restrict_signed(N, U_f, M, U_c, sign):
+    lib().mg_restrict_signed(N, U_f.ptr, M, U_c.ptr, sign)
+    _check()
+
+
+def restriction_table(N, M):
+    lo = np.empty(M, dtype=np.int32)
+    w = np.empty(M, dtype=np.float64)
+    load_library().mg_restriction_table(N, M, lo.ctypes.data, w.ctypes.data)
+    return lo, w
+
+
+def prolongation_table(N, M, axis):
+    owner = np.empty(M, dtype=np.int32)
+    hi = np.empty(M)
+    lo = np.empty(M)
+    load_library().mg_prolongation_table(N, M, axis, owner.ctypes.data, hi.ctypes.data, lo.ctypes.data)
+    return owner, hi, lo
+
+
+class CyclePlan:
+    """mg_cycle_load / mg_cycle_execute: the reference program's timed window
+    (src/MG_solver_CPU.cpp:156..429) over a cycle structure file."""
+
+    def __init__(self, path, fused=True, graph=False, report=True):
+        flags = (MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) | (MG_CYCLE_REPORT if report else 0)
+        self._plan = lib().mg_cycle_load(os.fsencode(path), flags)
+        _check()
+        if not self._plan:
+            raise MGError(f"cannot load cycle file {path}")
+
+    def execute(self, fetch_U=False):
+        res = CycleResult()
+        status = _lib.mg_cycle_execute(self._plan, C.byref(res))
+        _check()
+        out = dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
+                   records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
+                            for i in range(res.n_records)],
+                   report=res.report.decode() if res.report else "", U_ptr=res.U_dev)
+        if fetch_U:
+            U = np.empty((res.N, res.N))
+            _lib.mg_download(U.ctypes.data, res.U_dev, U.size)
+            out["U"] = U
+        return out
+
+    def close(self):
+        if self._plan and _initialised:
+            _lib.mg_cycle_destroy(self._plan)
+        self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_vcycle_file(path, N, N_min=8, steps=3, tol=1e-7, L=1.0):
+    """The synthetic V-cycle of SURVEY.md section 8d: header `steps 1 / N N_min`, one -1
+    per level down to the coarsest generated size, one exact solve, one 1 per level up."""
+    levels = 0
+    n = N
+    while n >= N_min:
+        levels += 1
+        n //= 2
+    with open(path, "w") as f:
+        f.write(f"{L} 0.0 0.0\n{steps} 1\n{N} {N_min}\n")
+        f.write("-1\n" * (levels - 1))
+        f.write(f"0\n{tol:.10f} 1\n")
+        f.write("1\n" * (levels - 1))
+        f.write("2")
+    return levels
+
+
+def write_wcycle_file(path, N, N_min=8, steps=3, tol=1e-7, L=1.0, depth=None):
+    """W-cycle with the recursion of the shipped src/Wcycle.txt (which stops after 4 of
+    its 6 generated levels); depth=None takes it down to the coarsest generated size."""
+    sizes = []
+    n = N
+    while n >= N_min:
+        sizes.append(n)
+        n //= 2
+    if depth is not None:
+        sizes = sizes[:depth]
+    last = len(sizes) - 1
+
+    def visit(level):
+        if level == last:
+            return ["0", f"{tol:.10f} 1"]
+        return ["-1"] + visit(level + 1) + ["1"] + ["-1"] + visit(level + 1) + ["1"]
+
+    nodes = ["-1"] + visit(1) + ["1"] if last >= 1 else visit(0)
+    with open(path, "w") as f:
+        f.write(f"{L} 0.0 0.0\n{steps} 1\n{N} {N_min}\n" + "\n".join(nodes) + "\n2")
+    return len(sizes)

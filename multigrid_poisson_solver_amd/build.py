@@ -1,0 +1,66 @@
+"""Build the engine IN-TREE with hipcc for gfx950: lib/libmgpoisson.so (kernels + C ABI +
+cycle driver) and bin/MG_HIP (the command-line program).  hipcc cross-compiles without a
+GPU.  -ffp-contract=off is part of the contract: results are bit-identical to the
+reference only without FMA contraction (hard part 4)."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib", "libmgpoisson.so")
+EXE = os.path.join(PKG, "bin", "MG_HIP")
+SOURCES = ["mg_kernels.hip", "mg_stream.hip", "mg_abi.cpp", "mg_tables.cpp", "mg_cycle.cpp", "mg_comm.cpp"]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; this engine is HIP-only)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "mg_internal.h"), os.path.join(ROOT, "include", "mg_hip.h"),
+                   os.path.abspath(__file__)]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-result"]
+    if force or _stale(LIB, deps):
+        objs = []
+        for s in srcs:
+            o = os.path.join(PKG, "lib", os.path.basename(s) + ".o")
+            if force or _stale(o, deps if s.endswith(".hip") else [s] + deps[len(srcs):]):
+                cmd = common + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+            objs.append(o)
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs + ["-lpthread"]
+        if os.path.exists(os.path.join(CSRC, "mg_comm.cpp")):
+            cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    if force or _stale(EXE, [LIB, os.path.join(CSRC, "mg_main.cpp")]):
+        cmd = [hipcc(), "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "mg_main.cpp"), "-o", EXE,
+               "-L" + os.path.dirname(LIB), "-lmgpoisson", "-Wl,-rpath,$ORIGIN/../lib"]
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,526 @@
+// mg_abi.cpp -- the extern "C" boundary (include/mg_hip.h): context, caching pool,
+// and the operator entry points that launch the kernels of mg_kernels.hip /
+// mg_stream.hip.  There is NO CPU fallback anywhere in this file: without a HIP
+// device every entry point fails loudly.
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+#include "mg_internal.h"
+
+namespace mg {
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+void fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    Context &c = ctx();
+    c.last_error = code;
+    c.last_error_text = buf;
+    fprintf(stderr, "[ ERROR ]: %s\n", buf);
+    if (c.abort_on_error) exit(1);  // the reference's convention: printf + exit(1)
+}
+
+bool hip_ok(hipError_t e, const char *what, const char *file, int line)
+{
+    if (e == hipSuccess) return true;
+    fail(MG_ERR_HIP, "HIP call failed: %s -> %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return false;
+}
+
+bool require_ready(const char *who)
+{
+    if (ctx().ready) return true;
+    fail(MG_ERR_NOT_INIT, "%s: mg_init() has not been called (or failed); there is no CPU fallback", who);
+    return false;
+}
+
+// ------------------------------------------------------------------ pool
+void *Pool::get(size_t bytes)
+{
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_.find(bytes);
+    if (it != free_.end()) {
+        void *p = it->second;
+        free_.erase(it);
+        live_[p] = bytes;
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // give cached blocks back and retry once
+        (void)hipGetLastError();
+        trim();
+        if (!MG_HIP(hipMalloc(&p, bytes))) return nullptr;
+    }
+    held_ += bytes;
+    live_[p] = bytes;
+    return p;
+}
+
+void Pool::put(void *p)
+{
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) {
+        fail(MG_ERR_ARG, "mg_free: pointer %p was not returned by mg_alloc", p);
+        return;
+    }
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+
+void Pool::trim()
+{
+    for (auto &kv : free_) {
+        (void)hipFree(kv.second);
+        held_ -= kv.first;
+    }
+    free_.clear();
+}
+
+Pool &scratch_pool()
+{
+    Context &c = ctx();
+    return c.active_pool ? *c.active_pool : c.pool;
+}
+
+double *partials(size_t n)
+{
+    Context &c = ctx();
+    if (n > c.partials_cap) {
+        // grown outside of any hot loop: the first call at a given size allocates
+        if (c.partials) c.retired.push_back(c.partials);  // a captured graph may still point at it
+        size_t cap = n < 4096 ? 4096 : n;
+        if (!MG_HIP(hipMalloc((void **)&c.partials, cap * sizeof(double)))) return nullptr;
+        c.partials_cap = cap;
+    }
+    return c.partials;
+}
+
+namespace {
+
+struct Scalars {  // slots inside ctx().scalars
+    enum { SMOOTH_ERR = 0, ANALYTIC_ERR = 1, CHECKSUM = 2 /* 2 x u64 */ };
+};
+
+bool grid_args_ok(const char *who, int N)
+{
+    if (N < 3) {
+        fail(MG_ERR_ARG, "%s: grid size N=%d is too small (need N >= 3)", who, N);
+        return false;
+    }
+    if (N > 46340) {  // N*N must fit the reference's int indexing
+        fail(MG_ERR_ARG, "%s: grid size N=%d overflows int indexing", who, N);
+        return false;
+    }
+    return true;
+}
+
+// h^2 as the reference forms it: pow(dx, 2) with dx = L/(double)(N-1)
+// (src/MG_solver_CPU.cpp:555,574,954), taken as dx*dx -- what every optimising build of
+// the reference computes; glibc's pow() differs by one ulp for a few grid sizes (2948,
+// 3504, ...: none a power of two), see oracle/mg_oracle.c:square.
+inline double spacing_sq(int N, double L)
+{
+    const double dx = L / (double)(N - 1);
+    return dx * dx;
+}
+
+void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step, double *error_dev,
+               double *D_out, int d_sign)
+{
+    Context &c = ctx();
+    hipStream_t s = c.stream;
+    const double dx2 = spacing_sq(N, L);
+    const double inv = 1.0 / dx2;
+    const size_t n = (size_t)N * N;
+
+    if (step <= 0) {  // no sweep: U_out = U_in
+        if (U_in) (void)hipMemcpyAsync(U_out, U_in, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+        else (void)hipMemsetAsync(U_out, 0, n * sizeof(double), s);
+        if (error_dev) k::smoothing_error(s, N, inv, U_out, F, error_dev);
+        if (D_out) k::residual(s, N, inv, U_out, F, D_out, d_sign);
+        return;
+    }
+
+    const bool stream = c.smoother == SMOOTHER_STREAM && k::stream_supported(N);
+    // sweeps per launch: the streaming kernel advances up to stream_max_steps() time
+    // levels per pass over HBM, the simple kernel one.  The launch count is made odd so
+    // that, ping-ponging between U_out and one partner buffer, the last launch lands in
+    // U_out and launch 0 never writes the buffer it reads.
+    const int smax = stream ? k::stream_max_steps() : 1;
+    int launches = (step + smax - 1) / smax;
+    if (launches % 2 == 0 && step > launches) launches += 1;
+    const bool needs_copy = (launches % 2 == 0);  // only smax == 1 with an even step
+    double *partner = const_cast<double *>(U_in);
+    bool own_partner = false;
+    if ((launches > 1 && !partner) || needs_copy) {
+        partner = (double *)scratch_pool().get(n * sizeof(double));
+        own_partner = true;
+        if (!partner) return;
+    }
+    const double *src = U_in;
+    int left = step;
+    for (int i = 0; i < launches; ++i) {
+        const int take = (left + (launches - i) - 1) / (launches - i);
+        const bool last = (i == launches - 1);
+        // odd count: dst alternates so that the last is U_out.  even count (own partner):
+        // start in the partner, the last launch then lands in U_out as well.
+        double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
+        if (stream) {
+            k::jacobi_stream(s, N, dx2, inv, src, F, dst, take, last ? error_dev : nullptr, last ? D_out : nullptr,
+                             d_sign, nullptr, 0, nullptr);
+        } else {
+            k::jacobi_simple(s, N, dx2, src, F, dst);
+        }
+        src = dst;
+        left -= take;
+    }
+    if (own_partner) scratch_pool().put(partner);  // stream-ordered: later users queue behind us
+    if (!stream) {
+        if (error_dev) k::smoothing_error(s, N, inv, U_out, F, error_dev);
+        if (D_out) k::residual(s, N, inv, U_out, F, D_out, d_sign);
+    }
+}
+
+}  // namespace
+}  // namespace mg
+
+using namespace mg;
+
+extern "C" {
+
+// ------------------------------------------------------------------ lifecycle
+int mg_init(int device)
+{
+    Context &c = ctx();
+    if (c.ready) return 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        fail(MG_ERR_HIP, "Cannot select GPU: no HIP device is visible (this engine has no CPU fallback)");
+        return 1;
+    }
+    if (device < 0 || device >= count) {
+        fail(MG_ERR_ARG, "Cannot select GPU %d (have %d)", device, count);
+        return 1;
+    }
+    if (!MG_HIP(hipSetDevice(device))) return 1;
+    hipDeviceProp_t prop;
+    if (MG_HIP(hipGetDeviceProperties(&prop, device))) c.n_cu = prop.multiProcessorCount;
+    if (!MG_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking))) return 1;
+    c.stream = c.own_stream;
+    if (!MG_HIP(hipMalloc((void **)&c.scalars, 64 * sizeof(double)))) return 1;
+    if (!MG_HIP(hipMalloc((void **)&c.gs_state, 4 * sizeof(int)))) return 1;
+    if (!MG_HIP(hipMemset(c.gs_state, 0, 4 * sizeof(int)))) return 1;
+    if (!MG_HIP(hipHostMalloc((void **)&c.host_scalars, 64 * sizeof(double), hipHostMallocDefault))) return 1;
+    if (!MG_HIP(hipHostMalloc((void **)&c.host_ints, 4 * sizeof(int), hipHostMallocDefault))) return 1;
+    c.device = device;
+    c.ready = true;
+    const char *sm = getenv("MG_SMOOTHER");
+    if (sm && *sm) mg_set_smoother(sm);
+    return 0;
+}
+
+void mg_finalize(void)
+{
+    Context &c = ctx();
+    if (!c.ready) return;
+    (void)hipStreamSynchronize(c.stream);
+    for (auto &kv : c.rtab) {
+        (void)hipFree(kv.second.lo);
+        (void)hipFree(kv.second.w);
+    }
+    for (auto &kv : c.ptab) {
+        (void)hipFree(kv.second.owner_row);
+        (void)hipFree(kv.second.owner_col);
+        (void)hipFree(kv.second.row_hi);
+        (void)hipFree(kv.second.row_lo);
+        (void)hipFree(kv.second.col_hi);
+        (void)hipFree(kv.second.col_lo);
+    }
+    c.rtab.clear();
+    c.ptab.clear();
+    c.pool.trim();
+    (void)hipFree(c.partials);
+    for (void *r : c.retired) (void)hipFree(r);
+    c.retired.clear();
+    c.partials = nullptr;
+    c.partials_cap = 0;
+    (void)hipFree(c.scalars);
+    (void)hipFree(c.gs_state);
+    (void)hipHostFree(c.host_scalars);
+    (void)hipHostFree(c.host_ints);
+    (void)hipStreamDestroy(c.own_stream);
+    c.own_stream = c.stream = nullptr;
+    c.ready = false;
+}
+
+void mg_set_stream(void *hip_stream)
+{
+    Context &c = ctx();
+    if (!require_ready("mg_set_stream")) return;
+    (void)hipStreamSynchronize(c.stream);
+    c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+}
+void *mg_get_stream(void) { return (void *)ctx().stream; }
+void mg_sync(void)
+{
+    if (!require_ready("mg_sync")) return;
+    MG_HIP(hipStreamSynchronize(ctx().stream));
+}
+int mg_last_error(void) { return ctx().last_error; }
+const char *mg_last_error_string(void) { return ctx().last_error_text.c_str(); }
+void mg_clear_error(void)
+{
+    ctx().last_error = 0;
+    ctx().last_error_text.clear();
+}
+void mg_set_abort_on_error(int on) { ctx().abort_on_error = on != 0; }
+int mg_set_smoother(const char *name)
+{
+    if (name && strcmp(name, "stream") == 0) ctx().smoother = SMOOTHER_STREAM;
+    else if (name && strcmp(name, "simple") == 0) ctx().smoother = SMOOTHER_SIMPLE;
+    else {
+        fail(MG_ERR_ARG, "mg_set_smoother: unknown smoother '%s' (stream|simple)", name ? name : "(null)");
+        return 1;
+    }
+    return 0;
+}
+const char *mg_version(void) { return "mgpoisson-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ memory
+double *mg_alloc(size_t n)
+{
+    if (!require_ready("mg_alloc")) return nullptr;
+    return (double *)ctx().pool.get(n * sizeof(double));
+}
+void mg_free(double *p)
+{
+    if (!p || !require_ready("mg_free")) return;
+    ctx().pool.put(p);
+}
+void mg_pool_trim(void)
+{
+    if (!ctx().ready) return;
+    (void)hipStreamSynchronize(ctx().stream);
+    ctx().pool.trim();
+}
+size_t mg_pool_bytes(void) { return ctx().pool.bytes_held(); }
+
+void mg_upload(double *dev, const double *host, size_t n)
+{
+    if (!require_ready("mg_upload")) return;
+    hipStream_t s = ctx().stream;
+    if (MG_HIP(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, s))) MG_HIP(hipStreamSynchronize(s));
+}
+void mg_download(double *host, const double *dev, size_t n)
+{
+    if (!require_ready("mg_download")) return;
+    hipStream_t s = ctx().stream;
+    if (MG_HIP(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, s))) MG_HIP(hipStreamSynchronize(s));
+}
+void mg_copy(double *dst, const double *src, size_t n)
+{
+    if (!require_ready("mg_copy")) return;
+    MG_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream));
+}
+void mg_fill_zero(double *dev, size_t n)
+{
+    if (!require_ready("mg_fill_zero")) return;
+    MG_HIP(hipMemsetAsync(dev, 0, n * sizeof(double), ctx().stream));
+}
+void mg_negate(int N, double *D)
+{
+    if (!require_ready("mg_negate") || !grid_args_ok("mg_negate", N)) return;
+    k::negate(ctx().stream, (size_t)N * N, D);
+}
+
+// ------------------------------------------------------------------ problem definition
+namespace {
+struct SourceJob {
+    int N;
+    double h, min_x, min_y;
+    double *F;
+};
+// src/MG_solver_CPU.cpp:468-493 on the host: libm exp(), the same bits as the
+// reference program produces on this machine
+void source_rows(size_t r0, size_t r1, void *arg)
+{
+    const SourceJob &j = *(const SourceJob *)arg;
+    const int N = j.N;
+    for (size_t r = r0; r < r1; ++r) {
+        for (int c = 0; c < N; ++c) {
+            double v = 0.0;
+            if (!(r == 0 || c == 0 || (int)r == N - 1 || c == N - 1)) {
+                const double x = (double)c * j.h + j.min_x;
+                const double y = (double)r * j.h + j.min_y;
+                v = 2.0 * x * (y - 1) * (y - 2.0 * x + x * y + 2.0) * std::exp(x - y);
+            }
+            j.F[r * (size_t)N + c] = v;
+        }
+    }
+}
+}  // namespace
+
+void mg_getSource(int N, double L, double *F, double min_x, double min_y)
+{
+    if (!require_ready("mg_getSource") || !grid_args_ok("mg_getSource", N)) return;
+    const char *mode = getenv("MG_SOURCE");
+    if (mode && strcmp(mode, "device") == 0) {  // <= 1 ulp from libm, no host pass
+        k::source_device(ctx().stream, N, L, F, min_x, min_y);
+        return;
+    }
+    const size_t n = (size_t)N * N;
+    double *host = nullptr;
+    if (!MG_HIP(hipHostMalloc((void **)&host, n * sizeof(double), hipHostMallocDefault))) return;
+    SourceJob job{N, L / (double)(N - 1), min_x, min_y, host};
+    parallel_for((size_t)N, source_rows, &job);
+    mg_upload(F, host, n);
+    (void)hipHostFree(host);
+}
+
+void mg_getAnalytic(int N, double L, double *U, double min_x, double min_y)
+{
+    if (!require_ready("mg_getAnalytic") || !grid_args_ok("mg_getAnalytic", N)) return;
+    k::analytic(ctx().stream, N, L, U, min_x, min_y);
+}
+
+void mg_analyticError(int N, double L, const double *U, double min_x, double min_y, double *error_host)
+{
+    if (!require_ready("mg_analyticError") || !grid_args_ok("mg_analyticError", N)) return;
+    Context &c = ctx();
+    double *slot = c.scalars + Scalars::ANALYTIC_ERR;
+    k::analytic_error(c.stream, N, L, U, min_x, min_y, slot);
+    if (error_host) mg_download(error_host, slot, 1);
+}
+
+// ------------------------------------------------------------------ operators
+void mg_getResidual(int N, double L, double *U, double *F, double *D)
+{
+    if (!require_ready("getResidual") || !grid_args_ok("getResidual", N)) return;
+    k::residual(ctx().stream, N, 1.0 / spacing_sq(N, L), U, F, D, +1);
+}
+
+void mg_doGridAddition(int N, double *U1, double *U2)
+{
+    if (!require_ready("doGridAddition") || !grid_args_ok("doGridAddition", N)) return;
+    k::add(ctx().stream, (size_t)N * N, U1, U2);
+}
+
+void mg_smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step, double *error_dev,
+                  double *D_out, int d_sign)
+{
+    if (!require_ready("mg_smooth_pp") || !grid_args_ok("mg_smooth_pp", N)) return;
+    if (U_in == U_out) {
+        fail(MG_ERR_ARG, "mg_smooth_pp: U_out must differ from U_in");
+        return;
+    }
+    smooth_pp(N, L, U_in, U_out, F, step, error_dev, D_out, d_sign < 0 ? -1 : +1);
+}
+
+void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *error)
+{
+    if (!require_ready("doSmoothing") || !grid_args_ok("doSmoothing", N)) return;
+    Context &c = ctx();
+    const size_t n = (size_t)N * N;
+    double *slot = c.scalars + Scalars::SMOOTH_ERR;
+    if (step > 0) {
+        // in-place semantics of the reference on top of the out-of-place kernels:
+        // sweep into pool scratch, then hand the result back into U
+        double *tmp = (double *)scratch_pool().get(n * sizeof(double));
+        if (!tmp) return;
+        smooth_pp(N, L, U, tmp, F, step, error ? slot : nullptr, nullptr, +1);
+        MG_HIP(hipMemcpyAsync(U, tmp, n * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+        scratch_pool().put(tmp);  // stream-ordered reuse: later users enqueue behind the copy
+    } else if (error) {
+        k::smoothing_error(c.stream, N, 1.0 / spacing_sq(N, L), U, F, slot);
+    }
+    if (error) mg_download(error, slot, 1);
+}
+
+void mg_doExactSolver(int N, double L, double *U, double *F, double target_error, int option)
+{
+    if (!require_ready("doExactSolver") || !grid_args_ok("doExactSolver", N)) return;
+    if (option == 0) {  // src/MG_solver_GPU.cu:1286-1289
+        fail(MG_ERR_UNSUPPORTED, "doExactSolver: the Inverse Matrix solver (option 0) is not available on the GPU path; use option 1");
+        return;
+    }
+    if (option != 1) return;  // the reference silently does nothing for other options (:630-637)
+    const double h2 = spacing_sq(N, L);
+    k::gauss_seidel(ctx().stream, N, h2, 1.0 / h2, U, F, target_error, ctx().gs_state);
+}
+
+int mg_lastExactSolverIterations(void)
+{
+    if (!require_ready("mg_lastExactSolverIterations")) return -1;
+    Context &c = ctx();
+    if (!MG_HIP(hipMemcpyAsync(c.host_ints, c.gs_state, 2 * sizeof(int), hipMemcpyDeviceToHost, c.stream))) return -1;
+    if (!MG_HIP(hipStreamSynchronize(c.stream))) return -1;
+    return c.host_ints[1];
+}
+
+void mg_restrict_signed(int N, const double *U_f, int M, double *U_c, int sign)
+{
+    if (!require_ready("doRestriction") || !grid_args_ok("doRestriction", N) || !grid_args_ok("doRestriction", M)) return;
+    const RestrictTable &t = restrict_table(N, M);
+    if (!t.lo) return;
+    k::restrict_gather(ctx().stream, N, U_f, M, U_c, t, sign < 0 ? -1 : +1);
+}
+
+void mg_doRestriction(int N, double *U_f, int M, double *U_c) { mg_restrict_signed(N, U_f, M, U_c, +1); }
+
+void mg_doProlongation(int N, double *U_c, int M, double *U_f)
+{
+    if (!require_ready("doProlongation") || !grid_args_ok("doProlongation", N) || !grid_args_ok("doProlongation", M)) return;
+    const ProlongTable &t = prolong_table(N, M);
+    if (!t.owner_row) return;
+    k::prolong(ctx().stream, N, U_c, M, nullptr, U_f, t);
+}
+
+void mg_prolongAdd(int N, const double *U_c, int M, const double *U_f_in, double *U_f_out)
+{
+    if (!require_ready("mg_prolongAdd") || !grid_args_ok("mg_prolongAdd", N) || !grid_args_ok("mg_prolongAdd", M)) return;
+    const ProlongTable &t = prolong_table(N, M);
+    if (!t.owner_row) return;
+    k::prolong(ctx().stream, N, U_c, M, U_f_in, U_f_out, t);
+}
+
+// ------------------------------------------------------------------ tables
+void mg_restriction_table(int N, int M, int *lo, double *w) { build_restriction_table(N, M, lo, w); }
+void mg_prolongation_table(int N, int M, int axis, int *owner, double *w_hi, double *w_lo)
+{
+    build_prolongation_table(N, M, axis, owner, w_hi, w_lo);
+}
+
+// ------------------------------------------------------------------ synthetic data
+void mg_fill_uniform(double *dst, size_t n, uint64_t seed)
+{
+    if (!require_ready("mg_fill_uniform")) return;
+    k::fill_uniform(ctx().stream, dst, n, seed);
+}
+
+void mg_checksum(const double *src, size_t n, uint64_t out[2])
+{
+    if (!require_ready("mg_checksum")) return;
+    Context &c = ctx();
+    uint64_t *slot = (uint64_t *)(c.scalars + Scalars::CHECKSUM);
+    k::checksum(c.stream, src, n, slot);
+    if (MG_HIP(hipMemcpyAsync(c.host_scalars, slot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream)) &&
+        MG_HIP(hipStreamSynchronize(c.stream))) {
+        memcpy(out, c.host_scalars, 2 * sizeof(uint64_t));
+    }
+}
+
+}  // extern "C"

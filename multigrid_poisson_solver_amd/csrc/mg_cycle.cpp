@@ -1,0 +1,612 @@
+// mg_cycle.cpp -- the cycle-structure-file driver and the level stack.
+//
+// Keeps the reference's driver design (BASELINE.json north_star): the multigrid cycle
+// is not hard-coded but interpreted, node by node, from a text file
+// (README.md:43-128), and the per-level grids U/F/D live in a doubly linked list that
+// is pushed on restriction and popped on prolongation (src/linkedlist.{h,cpp}).
+// What changes: the list hands out DEVICE arrays from a plan-private pool, the driver's
+// own host loops over U/F/D (memset :213,:256; sign flip :277-280; tempU :353,:371;
+// final error :434-445) become engine calls, and the smoothing errors stay on the
+// device until the window ends so the window has no host synchronisation.
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mg_internal.h"
+
+namespace mg {
+namespace {
+
+// ---------------------------------------------------------------------------
+// LevelList: the reference's LinkedList (src/linkedlist.h:32-60) on device arrays
+// ---------------------------------------------------------------------------
+struct LevelNode {  // src/linkedlist.h:4-30
+    int N = 0;
+    double *U = nullptr, *F = nullptr, *D = nullptr;
+    LevelNode *nextNode = nullptr, *prevNode = nullptr;
+    int step = 0;
+    double smoothingError = 0.0;
+};
+
+class LevelList {
+public:
+    explicit LevelList(Pool *pool) : pool_(pool) {}
+    ~LevelList() { clear(); }
+    void clear()
+    {
+        while (lastNode_) Remove_back();
+        init_ = 1;
+    }
+    void Push_back(int n)  // src/linkedlist.cpp:28-44 (+ ListNode::ListNode :7-16)
+    {
+        LevelNode *nd = new LevelNode;
+        const size_t bytes = (size_t)n * n * sizeof(double);
+        nd->N = n;
+        nd->U = (double *)pool_->get(bytes);
+        nd->F = (double *)pool_->get(bytes);
+        nd->D = (double *)pool_->get(bytes);
+        if (!firstNode_) {
+            firstNode_ = lastNode_ = nd;
+            return;
+        }
+        nd->prevNode = lastNode_;
+        lastNode_->nextNode = nd;
+        lastNode_ = nd;
+    }
+    void Remove_back()  // src/linkedlist.cpp:46-69
+    {
+        LevelNode *nd = lastNode_;
+        if (!nd) return;
+        pool_->put(nd->U);
+        pool_->put(nd->F);
+        pool_->put(nd->D);
+        if (firstNode_ == lastNode_) {
+            firstNode_ = lastNode_ = nullptr;
+        } else {
+            lastNode_ = nd->prevNode;
+            lastNode_->nextNode = nullptr;
+            if (firstNode_ == lastNode_) init_ = 0;
+        }
+        delete nd;
+    }
+    LevelNode *last() { return lastNode_; }
+    int depth() const
+    {
+        int d = 0;
+        for (LevelNode *p = firstNode_; p; p = p->nextNode) ++d;
+        return d;
+    }
+    int Get_N() const { return lastNode_->N; }
+    int Get_prev_N() const { return lastNode_->prevNode->N; }
+    int Get_init() const { return init_; }
+    void Set_init(int r) { init_ = r; }
+    bool Is_firstNode() const { return firstNode_ == lastNode_ && firstNode_ != nullptr; }
+
+private:
+    Pool *pool_;
+    LevelNode *firstNode_ = nullptr, *lastNode_ = nullptr;
+    int init_ = 1;  // 1 until the list has collapsed back to the first node once
+};
+
+struct Text {
+    std::string s;
+    void printf(const char *fmt, ...)
+    {
+        char tmp[256];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_end(ap);
+        s += tmp;
+    }
+};
+
+// report entries: literal text or a smoothing block whose error is filled in later
+struct ReportItem {
+    std::string text;
+    int record = -1;  // >= 0: "~Smoothing~" block of records[record]
+};
+
+}  // namespace
+}  // namespace mg
+
+using namespace mg;
+
+struct mg_cycle_plan {
+    int flags = 0;
+    std::string path;
+    // header, src/MG_solver_CPU.cpp:103-109
+    double L = 1.0, min_x = 0.0, min_y = 0.0;
+    int con_step = 0, con_N = 0, N_max = 0, N_min = 0;
+    std::vector<int> sizes;          // N_array :111-146
+    std::vector<double> tokens;      // everything after the header
+    Pool pool;                       // plan-private arena (stable addresses for graph replay)
+    LevelList *levels = nullptr;
+    double *F_finest = nullptr;      // getSource(N_max), evaluated once at load (:153)
+    double *err_dev = nullptr;       // one slot per smoothing record
+    size_t err_cap = 0;
+    std::vector<mg_node_record> records;
+    std::vector<ReportItem> report_items;
+    std::string report;
+    double *final_U = nullptr;
+    int final_N = 0;
+    // graph replay
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ready = false, graph_failed = false;
+    int warm_runs = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+const double TRIGGER = 0.01;  // src/MG_solver_CPU.cpp:99
+
+struct Exec {
+    mg_cycle_plan *p;
+    Context &c;
+    size_t tok = 0;
+    int at = 0;  // len_flag
+    int status = 0;
+    bool capturing = false;
+
+    bool next(double *v)
+    {
+        if (tok >= p->tokens.size()) return false;
+        *v = p->tokens[tok++];
+        return true;
+    }
+    bool next_int(int *v)
+    {
+        double d;
+        if (!next(&d)) return false;
+        *v = (int)d;
+        return true;
+    }
+};
+
+int add_record(mg_cycle_plan *p, int node, int N, int steps)
+{
+    mg_node_record r{node, N, steps, 0.0};
+    p->records.push_back(r);
+    return (int)p->records.size() - 1;
+}
+
+void report_text(mg_cycle_plan *p, const char *t)
+{
+    if (!(p->flags & MG_CYCLE_REPORT)) return;
+    ReportItem it;
+    it.text = t;
+    p->report_items.push_back(it);
+}
+void report_smoothing(mg_cycle_plan *p, int record)
+{
+    if (!(p->flags & MG_CYCLE_REPORT)) return;
+    ReportItem it;
+    it.record = record;
+    p->report_items.push_back(it);
+}
+
+double *error_slot(mg_cycle_plan *p, int record) { return p->err_dev + record; }
+
+// smoothing with the error trigger, src/MG_solver_CPU.cpp:194-230 / :376-402: one sweep
+// at a time, each followed by a host-visible error -- inherently synchronous
+int trigger_smoothing(Exec &x, LevelNode *lv)
+{
+    double slope = TRIGGER + 1.0, before = 0.0;
+    lv->step = 0;
+    while (slope > TRIGGER) {
+        mg_doSmoothing(lv->N, x.p->L, lv->U, lv->F, 1, &lv->smoothingError);
+        if (x.c.last_error) return lv->step;
+        lv->step += 1;
+        if (lv->step == 1) {
+            before = lv->smoothingError;
+            continue;
+        }
+        slope = std::fabs(lv->smoothingError - before);
+        before = lv->smoothingError;
+    }
+    return lv->step;
+}
+
+// fixed-step smoothing of the last level, result in lv->U.  zero_start: the driver's
+// memset(U,0) (:256) is folded into the first sweep.  want_D: also produce -residual in
+// lv->D (getResidual :268 and the sign flip :277-280 folded into the last sweep).
+void smooth_level(Exec &x, LevelNode *lv, int step, bool zero_start, bool want_D, int record)
+{
+    mg_cycle_plan *p = x.p;
+    const size_t n = (size_t)lv->N * lv->N;
+    if (p->flags & MG_CYCLE_FUSED) {
+        if (zero_start) {
+            mg_smooth_pp(lv->N, p->L, nullptr, lv->U, lv->F, step, error_slot(p, record), want_D ? lv->D : nullptr, -1);
+        } else if (!want_D) {
+            // post-smoothing: D of this level is dead (consumed by the restriction on
+            // the way down), use it as the ping-pong partner and swap
+            mg_smooth_pp(lv->N, p->L, lv->U, lv->D, lv->F, step, error_slot(p, record), nullptr, -1);
+            std::swap(lv->U, lv->D);
+        } else {
+            double *tmp = (double *)p->pool.get(n * sizeof(double));
+            mg_smooth_pp(lv->N, p->L, lv->U, tmp, lv->F, step, error_slot(p, record), lv->D, -1);
+            std::swap(lv->U, tmp);
+            p->pool.put(tmp);
+        }
+        return;
+    }
+    // literal operator sequence of the reference
+    if (zero_start) mg_fill_zero(lv->U, n);
+    {
+        double *tmp = (double *)p->pool.get(n * sizeof(double));
+        mg_smooth_pp(lv->N, p->L, lv->U, tmp, lv->F, step, error_slot(p, record), nullptr, +1);
+        mg_copy(lv->U, tmp, n);
+        p->pool.put(tmp);
+    }
+    if (want_D) {
+        mg_getResidual(lv->N, p->L, lv->U, lv->F, lv->D);
+        mg_negate(lv->N, lv->D);
+    }
+}
+
+// one pass over the node program == the reference's while loop :158-426
+void run_nodes(Exec &x)
+{
+    mg_cycle_plan *p = x.p;
+    LevelList &cycle = *p->levels;
+    const bool fused = (p->flags & MG_CYCLE_FUSED) != 0;
+
+    for (;;) {
+        int node;
+        if (!x.next_int(&node)) break;  // end of file without a 2
+        if (node == 2) break;           // :162-164
+        if (x.c.last_error) { x.status = 10; break; }
+
+        if (node == -1) {  // :169-300
+            int step = 0, next_N = 0;
+            if (p->con_step == 0) { if (!x.next_int(&step)) { x.status = 3; break; } }
+            else step = p->con_step;
+            if (p->con_N == 0) { if (!x.next_int(&next_N)) { x.status = 3; break; } }
+            else {
+                if (x.at + 1 >= (int)p->sizes.size()) { x.status = 4; break; }  // reference: out-of-bounds read (D2)
+                next_N = p->sizes[++x.at];
+            }
+            if (step == 0) continue;  // :241-243, :296-299 (FMG stub)
+            if (next_N < 3) { x.status = 7; break; }
+
+            LevelNode *lv = cycle.last();
+            const bool keep = (cycle.Get_init() == 0 && cycle.Is_firstNode());  // :209-214, :252-257
+            int rec;
+            if (step == -1) {
+                if (x.capturing) { x.status = 8; break; }
+                if (!keep) mg_fill_zero(lv->U, (size_t)lv->N * lv->N);
+                const int done = trigger_smoothing(x, lv);
+                rec = add_record(p, -1, lv->N, done);
+                p->records[rec].error = lv->smoothingError;
+                mg_upload(error_slot(p, rec), &lv->smoothingError, 1);
+                mg_getResidual(lv->N, p->L, lv->U, lv->F, lv->D);  // :239
+                mg_negate(lv->N, lv->D);                           // :277-280
+            } else {
+                rec = add_record(p, -1, lv->N, step);
+                smooth_level(x, lv, step, !keep, true, rec);
+            }
+            report_smoothing(p, rec);
+
+            cycle.Push_back(next_N);                                            // :283
+            mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);      // :287
+            report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
+        } else if (node == 0) {  // :305-324
+            double tol;
+            int option;
+            if (!x.next(&tol) || !x.next_int(&option)) { x.status = 3; break; }
+            LevelNode *lv = cycle.last();
+            if (x.capturing && lv->N > k::gs_single_workgroup_max_n()) { x.status = 8; break; }
+            mg_doExactSolver(lv->N, p->L, lv->U, lv->F, tol, option);
+            if (x.c.last_error) { x.status = 5; break; }
+            add_record(p, 0, lv->N, 0);
+            if (p->flags & MG_CYCLE_REPORT) {
+                Text t;
+                t.printf("          ~Exact Solver~\n");
+                t.printf("Current Grid Size N = %d\n", lv->N);
+                if (option == 0) t.printf("   Use Exact Solver = Inverse Matrix\n");
+                if (option == 1) t.printf("   Use Exact Solver = GaussSeidel Even / Odd\n");
+                t.printf("       Target Error = %.3e\n", tol);
+                report_text(p, t.s.c_str());
+            }
+        } else if (node == 1) {  // :329-424
+            int step;
+            if (p->con_step == 0) { if (!x.next_int(&step)) { x.status = 3; break; } }
+            else step = p->con_step;
+            if (p->con_N != 0) x.at--;
+            if (cycle.depth() < 2) { x.status = 6; break; }
+
+            LevelNode *coarse = cycle.last();
+            LevelNode *fine = coarse->prevNode;
+            if (fused) {
+                // tempU (:353), doProlongation (:354) and doGridAddition (:368) in one pass;
+                // the fine level's D is dead here and serves as the output buffer
+                mg_prolongAdd(coarse->N, coarse->U, fine->N, fine->U, fine->D);
+                std::swap(fine->U, fine->D);
+                cycle.Remove_back();  // :363
+            } else {
+                const size_t nf = (size_t)fine->N * fine->N;
+                double *tempU = (double *)p->pool.get(nf * sizeof(double));  // :353
+                mg_doProlongation(coarse->N, coarse->U, fine->N, tempU);      // :354
+                cycle.Remove_back();                                          // :363
+                mg_doGridAddition(fine->N, fine->U, tempU);                   // :368
+                p->pool.put(tempU);                                           // :371
+            }
+            report_text(p, "             *\n             |\nProlongation |\n             |\n             *\n");
+
+            if (step == 0) continue;  // :409-411
+            LevelNode *lv = cycle.last();
+            int rec;
+            if (step == -1) {
+                if (x.capturing) { x.status = 8; break; }
+                const int done = trigger_smoothing(x, lv);
+                rec = add_record(p, 1, lv->N, done);
+                p->records[rec].error = lv->smoothingError;
+                mg_upload(error_slot(p, rec), &lv->smoothingError, 1);
+            } else {
+                rec = add_record(p, 1, lv->N, step);
+                smooth_level(x, lv, step, false, false, rec);
+            }
+            report_smoothing(p, rec);
+        }
+        // any other token: ignored, as the reference does
+    }
+}
+
+// reset the level stack to the state right after getSource (:149-153)
+void reset_levels(mg_cycle_plan *p)
+{
+    LevelList &cycle = *p->levels;
+    // keep the finest level (its F never changes); drop anything a broken file left over
+    while (cycle.depth() > 1) cycle.Remove_back();
+    cycle.Set_init(1);
+    p->records.clear();
+    p->report_items.clear();
+}
+
+bool uses_trigger(const mg_cycle_plan *p)
+{
+    if (p->con_step == -1) return true;
+    if (p->con_step != 0) return false;
+    for (double t : p->tokens)
+        if (t == -1.0) return true;  // conservative: a manual step of -1 may appear
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+mg_cycle_plan *mg_cycle_load(const char *path, int flags)
+{
+    if (!require_ready("mg_cycle_load")) return nullptr;
+    std::ifstream f(path);
+    if (!f.is_open()) {
+        fail(MG_ERR_CYCLE_FILE, "Cannot open file %s", path);  // src/MG_solver_CPU.cpp:65-68
+        return nullptr;
+    }
+    mg_cycle_plan *p = new mg_cycle_plan;
+    p->flags = flags;
+    p->path = path;
+    if (!(f >> p->L >> p->min_x >> p->min_y >> p->con_step >> p->con_N >> p->N_max >> p->N_min)) {
+        fail(MG_ERR_CYCLE_FILE, "%s: malformed cycle structure header", path);
+        delete p;
+        return nullptr;
+    }
+    if (p->N_max < 3 || p->N_max > 46340 || (p->con_N != 0 && p->N_min < 1)) {
+        fail(MG_ERR_CYCLE_FILE, "%s: unusable grid sizes N_max=%d N_min=%d", path, p->N_max, p->N_min);
+        delete p;
+        return nullptr;
+    }
+    std::string tok;
+    while (f >> tok) {
+        char *end = nullptr;
+        const double v = strtod(tok.c_str(), &end);
+        if (end == tok.c_str()) break;  // a non-numeric token ends the program
+        p->tokens.push_back(v);
+    }
+    if (p->con_N == 1) {  // :111-131
+        for (int n = p->N_max; n >= p->N_min && n > 0; n /= 2) p->sizes.push_back(n);
+    } else if (p->con_N == 2) {  // :132-146
+        for (int n = p->N_max; n >= p->N_min; --n) p->sizes.push_back(n);
+    }
+    size_t smoothing_nodes = 0;
+    for (double t : p->tokens)
+        if (t == -1.0 || t == 1.0) ++smoothing_nodes;
+    p->err_cap = smoothing_nodes + 8;
+    p->err_dev = (double *)p->pool.get(p->err_cap * sizeof(double));
+    p->levels = new LevelList(&p->pool);
+    p->levels->Push_back(p->N_max);  // :149
+    LevelNode *top = p->levels->last();
+    if (!top->U || !top->F || !top->D || !p->err_dev) {
+        mg_cycle_destroy(p);
+        return nullptr;
+    }
+    mg_getSource(top->N, p->L, top->F, p->min_x, p->min_y);  // :153
+    p->F_finest = top->F;
+    (void)hipEventCreate(&p->ev0);
+    (void)hipEventCreate(&p->ev1);
+    mg_sync();
+    return p;
+}
+
+int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_cycle_execute") || !p) return 1;
+    Context &c = ctx();
+    hipStream_t s = c.stream;
+    memset(out, 0, sizeof *out);
+
+    const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !uses_trigger(p) &&
+                            !p->graph_failed;
+    int status = 0;
+    mg_sync();
+    const auto t0 = std::chrono::steady_clock::now();  // :156
+    (void)hipEventRecord(p->ev0, s);
+
+    if (want_graph && p->graph_ready) {
+        // the node program is static: replay it.  records/report keep their structure,
+        // only the error values are refreshed below.
+        if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+    } else {
+        reset_levels(p);
+        c.active_pool = &p->pool;
+        Exec x{p, c};
+        const bool capture_now = want_graph && p->warm_runs >= 1;  // run 0 warms pool + tables
+        if (capture_now) {
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) x.capturing = true;
+            else { (void)hipGetLastError(); p->graph_failed = true; }
+        }
+        run_nodes(x);
+        status = x.status;
+        if (x.capturing) {
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (e == hipSuccess && status == 0 && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                p->graph = g;
+                p->graph_ready = true;
+                if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+            } else {
+                (void)hipGetLastError();
+                if (g) (void)hipGraphDestroy(g);
+                p->graph_failed = true;
+                if (status == 8) status = 0;
+                // fall back to an eager pass so this execute still produces the result
+                reset_levels(p);
+                Exec y{p, c};
+                run_nodes(y);
+                status = y.status;
+            }
+        }
+        c.active_pool = nullptr;
+        p->warm_runs++;
+        LevelNode *last = p->levels->last();
+        p->final_U = last->U;
+        p->final_N = last->N;
+    }
+
+    (void)hipEventRecord(p->ev1, s);
+    mg_sync();
+    const auto t1 = std::chrono::steady_clock::now();  // :429
+    float dev_ms = 0.f;
+    (void)hipEventElapsedTime(&dev_ms, p->ev0, p->ev1);
+
+    // smoothing errors: one download for the whole window
+    std::vector<double> errs(p->records.size(), 0.0);
+    if (!errs.empty()) {
+        std::vector<double> all(p->records.size());
+        mg_download(all.data(), p->err_dev, all.size());
+        for (size_t i = 0; i < p->records.size(); ++i)
+            if (p->records[i].node != 0) p->records[i].error = all[i];
+    }
+
+    double mg_error = 0.0;
+    mg_analyticError(p->final_N, p->L, p->final_U, p->min_x, p->min_y, &mg_error);  // :434-445
+
+    if (p->flags & MG_CYCLE_REPORT) {
+        Text t;
+        for (const ReportItem &it : p->report_items) {
+            if (it.record < 0) {
+                t.s += it.text;
+                continue;
+            }
+            const mg_node_record &r = p->records[it.record];  // :261-264, :418-421
+            t.printf("          ~Smoothing~\n");
+            t.printf("Current Grid Size N = %d\n", r.N);
+            t.printf("    Smoothing Steps = %d\n", r.steps);
+            t.printf("              Error = %lf\n", r.error);
+        }
+        t.printf("\n\n===== Final Result =====\n    Error = %lf\n", mg_error);  // :448-450
+        p->report = t.s;
+    }
+
+    out->status = status ? status : (c.last_error ? 10 : 0);
+    out->N = p->final_N;
+    out->U_dev = p->final_U;
+    out->mg_error = mg_error;
+    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->device_ms = dev_ms;
+    out->n_records = (int)p->records.size();
+    out->records = p->records.data();
+    out->report = p->report.c_str();
+    return out->status;
+}
+
+void mg_cycle_destroy(mg_cycle_plan *p)
+{
+    if (!p) return;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->levels) {
+        p->levels->clear();
+        delete p->levels;
+    }
+    if (p->err_dev) p->pool.put(p->err_dev);
+    p->pool.trim();
+    delete p;
+}
+
+// src/MG_solver_CPU.cpp:735-754 on a device array: top row first, "%lf" comma separated
+int mg_print2File(int N, const double *U_dev, const char *file_name)
+{
+    if (!require_ready("mg_print2File")) return 1;
+    std::vector<double> U((size_t)N * N);
+    mg_download(U.data(), U_dev, U.size());
+    FILE *o = fopen(file_name, "w");
+    if (!o) {
+        fail(MG_ERR_ARG, "Cannot open file %s", file_name);
+        return 1;
+    }
+    for (int j = N - 1; j >= 0; --j)
+        for (int i = 0; i < N; ++i) fprintf(o, i == N - 1 ? "%lf\n" : "%lf,", U[i + (size_t)N * j]);
+    fclose(o);
+    return 0;
+}
+
+// The reference program (src/MG_solver_CPU.cpp:36-462) on the engine:
+//   MG_HIP N_THREADS_OMP cycle_filename.txt
+// argv[1] is accepted for command-line compatibility (there are no OpenMP loops left).
+int mg_cycle_main(int argc, char **argv)
+{
+    if (argc != 3) {  // :51-54
+        printf("[ ERROR ]: Wrong input numbers of parameter.\n");
+        return 1;
+    }
+    printf("OpenMP threads = %d\n", atoi(argv[1]));       // :59
+    printf("Cycle structure file name = %s\n", argv[2]);  // :63
+    const char *dev = getenv("MG_DEVICE");
+    if (mg_init(dev ? atoi(dev) : 0) != 0) return 1;
+    mg_cycle_plan *plan = mg_cycle_load(argv[2], MG_CYCLE_FUSED | MG_CYCLE_REPORT);
+    if (!plan) {
+        printf("[ ERROR ]: Cannot open file %s\n", argv[2]);  // :66
+        return 1;
+    }
+    mg_cycle_result res;
+    const int status = mg_cycle_execute(plan, &res);
+    if (status != 0) {
+        printf("[ ERROR ]: cycle structure file is malformed (status %d)\n", status);
+        mg_cycle_destroy(plan);
+        return 1;
+    }
+    fputs(res.report, stdout);
+    printf("Time Used = %lf (ms)\n", res.time_ms);  // :451
+    // output name: "Sol_" + backend tag + argv[2], as the reference builds "Sol_CPU_"/"Sol_GPU_" (:454-456)
+    std::string name = std::string("Sol_HIP_") + argv[2];
+    mg_print2File(res.N, res.U_dev, name.c_str());
+    printf("Output file name = %s\n", name.c_str());  // :459
+    mg_cycle_destroy(plan);
+    mg_finalize();
+    return 0;
+}
+
+}  // extern "C"

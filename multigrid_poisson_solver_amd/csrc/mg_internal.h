@@ -1,0 +1,138 @@
+// mg_internal.h -- engine-internal declarations shared by the host files and the
+// kernel file.  Nothing here is part of the C ABI (include/mg_hip.h).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mg_hip.h"
+
+namespace mg {
+
+// ---------------------------------------------------------------------------
+// errors: the reference printf+exit(1)s (src/MG_solver_GPU.cu:58-62,1286-1289)
+// ---------------------------------------------------------------------------
+enum ErrorCode {
+    MG_OK = 0,
+    MG_ERR_HIP = 1,
+    MG_ERR_ARG = 2,
+    MG_ERR_UNSUPPORTED = 3,
+    MG_ERR_NOT_INIT = 4,
+    MG_ERR_CYCLE_FILE = 5,
+    MG_ERR_COMM = 6,
+};
+
+void fail(int code, const char *fmt, ...);
+bool hip_ok(hipError_t e, const char *what, const char *file, int line);
+#define MG_HIP(expr) ::mg::hip_ok((expr), #expr, __FILE__, __LINE__)
+
+// ---------------------------------------------------------------------------
+// device tables for restriction / prolongation, cached per (N, M)
+// ---------------------------------------------------------------------------
+struct RestrictTable {
+    int *lo = nullptr;     // [M] lower-left fine index
+    double *w = nullptr;   // [M] weight a (resp. c)
+};
+struct ProlongTable {
+    int *owner_row = nullptr, *owner_col = nullptr;        // [M]
+    double *row_hi = nullptr, *row_lo = nullptr;           // [M] (c3y - f_y), (f_y - c1y)
+    double *col_hi = nullptr, *col_lo = nullptr;           // [M] (c2x - f_x), (f_x - c1x)
+    double c_dx = 0.0;
+};
+
+// ---------------------------------------------------------------------------
+// caching device pool (replaces malloc/free of the level arrays)
+// ---------------------------------------------------------------------------
+class Pool {
+public:
+    void *get(size_t bytes);
+    void put(void *p);
+    void trim();
+    size_t bytes_held() const { return held_; }
+private:
+    std::multimap<size_t, void *> free_;   // size -> block
+    std::map<void *, size_t> live_;        // block -> size
+    size_t held_ = 0;
+};
+
+enum Smoother { SMOOTHER_STREAM = 0, SMOOTHER_SIMPLE = 1 };
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    Pool pool;
+    Pool *active_pool = nullptr;           // plan-private arena while a cycle plan executes
+    Smoother smoother = SMOOTHER_STREAM;
+    // reduction scratch: per-block partial sums + scalar slots
+    double *partials = nullptr;
+    size_t partials_cap = 0;
+    std::vector<void *> retired;          // outgrown scratch, kept alive for captured graphs
+    double *scalars = nullptr;            // [64] device scalars (errors, norms)
+    int *gs_state = nullptr;              // [4]: done flag, iteration count, ...
+    double *host_scalars = nullptr;       // pinned [64]
+    int *host_ints = nullptr;             // pinned [4]
+    std::map<std::pair<int, int>, RestrictTable> rtab;
+    std::map<std::pair<int, int>, ProlongTable> ptab;
+    int last_error = 0;
+    std::string last_error_text;
+    bool abort_on_error = true;
+};
+
+Context &ctx();
+bool require_ready(const char *who);
+double *partials(size_t n);   // device scratch for at least n doubles
+Pool &scratch_pool();         // where operator-internal scratch comes from
+
+const RestrictTable &restrict_table(int N, int M);
+const ProlongTable &prolong_table(int N, int M);
+// host-side builders (exact reference expressions)
+void build_restriction_table(int N, int M, int *lo, double *w);
+void build_prolongation_table(int N, int M, int axis, int *owner, double *w_hi, double *w_lo);
+bool restriction_table_in_bounds(int N, int M, const int *lo);
+
+// small host helper: run fn(begin,end) over [0,n) on the host threads
+void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg);
+
+// ---------------------------------------------------------------------------
+// kernel launchers (mg_kernels.hip).  All enqueue on s and return immediately.
+// ---------------------------------------------------------------------------
+namespace k {
+// one Jacobi sweep in correction form, in -> out (in == nullptr: all zero)
+void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out);
+// D = sign * (inv*(star - 4U) - F), rim sign*0
+void residual(hipStream_t s, int N, double inv, const double *U, const double *F, double *D, int sign);
+// doSmoothing's error: *out = (S+S)/N/N, S = sum over (row+col) even interior of |inv*star-F|
+void smoothing_error(hipStream_t s, int N, double inv, const double *U, const double *F, double *out);
+// temporally blocked streaming smoother (mg_stream.hip): steps <= stream_max_steps()
+int  stream_max_steps();
+bool stream_supported(int N);
+void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F,
+                   double *out, int steps, double *err_out, double *D_out, int d_sign,
+                   const double *coarse, int Nc, const ProlongTable *pt);
+void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
+// Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
+void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);
+void add(hipStream_t s, size_t n, double *a, const double *b);
+void negate(hipStream_t s, size_t n, double *a);
+void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y);
+void analytic(hipStream_t s, int N, double L, double *U, double min_x, double min_y);
+void analytic_error(hipStream_t s, int N, double L, const double *U, double min_x, double min_y, double *out);
+void fill_uniform(hipStream_t s, double *dst, size_t n, uint64_t seed);
+void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2]*/);
+// red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]
+void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol,
+                  int *state);
+int  gs_single_workgroup_max_n();
+}  // namespace k
+
+}  // namespace mg

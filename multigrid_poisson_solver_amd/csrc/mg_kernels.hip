@@ -1,0 +1,515 @@
+// mg_kernels.hip -- fp64 HIP kernels (gfx950 / CDNA4, wave64) for the multigrid
+// operators, plus their launchers.  Built with -ffp-contract=off: every expression
+// keeps the association order of the reference CPU code so the output arrays are
+// bit-identical (hard part 4).
+//
+// Layout: row-major N x N doubles, index = col + N*row, boundary included
+// (src/MG_solver_CPU.cpp:484).  All kernels are HBM-bound streaming kernels: lanes map
+// to consecutive columns so every wave instruction touches one contiguous 512 B
+// segment of a row.  The temporally blocked smoother lives in mg_stream.hip.
+#include <hip/hip_runtime.h>
+
+#include "mg_internal.h"
+
+namespace mg {
+namespace k {
+
+namespace {
+
+constexpr int TB = 256;       // threads per block for the streaming kernels
+constexpr int ROWS_PB = 4;    // rows per block
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over the block in a fixed order; valid in thread 0
+__device__ __forceinline__ double block_sum(double v)
+{
+    __shared__ double sm[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect sm against a previous use
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += sm[i];
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool rim(int r, int c, int N)
+{
+    return r == 0 || c == 0 || r == N - 1 || c == N - 1;
+}
+
+// 5-point sum in the reference's order: row+1, row-1, col+1, col-1, then -4*centre
+// (src/MG_solver_CPU.cpp:560,:590,:611)
+__device__ __forceinline__ double star_minus4(const double *__restrict__ A, size_t p, int N)
+{
+    return A[p + N] + A[p - N] + A[p + 1] + A[p - 1] - 4 * A[p];
+}
+
+// ---------------------------------------------------------------- Jacobi, one sweep
+// src/MG_solver_CPU.cpp:587-599: U = U_old + 0.25*(star(U_old) - 4 U_old - dx^2 F)
+template <bool ZERO_IN>
+__global__ __launch_bounds__(TB) void k_jacobi_simple(int N, double dx2, const double *__restrict__ in,
+                                                      const double *__restrict__ F, double *__restrict__ out)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * ROWS_PB;
+#pragma unroll
+    for (int k = 0; k < ROWS_PB; ++k) {
+        const int r = r0 + k;
+        if (r >= N) return;
+        const size_t p = (size_t)r * N + c;
+        double v;
+        if (ZERO_IN) {
+            v = rim(r, c, N) ? 0.0 : 0.0 + 0.25 * (0.0 - dx2 * F[p]);
+        } else {
+            v = in[p];
+            if (!rim(r, c, N)) v = v + 0.25 * (star_minus4(in, p, N) - dx2 * F[p]);
+        }
+        out[p] = v;
+    }
+}
+
+// ---------------------------------------------------------------- residual
+// src/MG_solver_CPU.cpp:554-564 (and the driver's sign flip :277-280 when sign < 0)
+__global__ __launch_bounds__(TB) void k_residual(int N, double inv, const double *__restrict__ U,
+                                                 const double *__restrict__ F, double *__restrict__ D, int sign)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * ROWS_PB;
+#pragma unroll
+    for (int k = 0; k < ROWS_PB; ++k) {
+        const int r = r0 + k;
+        if (r >= N) return;
+        const size_t p = (size_t)r * N + c;
+        double v = 0.0;
+        if (!rim(r, c, N)) v = inv * star_minus4(U, p, N) - F[p];
+        D[p] = sign < 0 ? -v : v;
+    }
+}
+
+// ---------------------------------------------------------------- smoothing error
+// src/MG_solver_CPU.cpp:607-622: both sums run over (row+col) even interior points
+__global__ __launch_bounds__(TB) void k_smoothing_error(int N, double inv, const double *__restrict__ U,
+                                                        const double *__restrict__ F, double *__restrict__ part)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    const int r0 = blockIdx.y * ROWS_PB;
+    double acc = 0.0;
+    if (c < N) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PB; ++k) {
+            const int r = r0 + k;
+            if (r < N && !rim(r, c, N) && ((r + c) & 1) == 0) {
+                const size_t p = (size_t)r * N + c;
+                acc += fabs(inv * star_minus4(U, p, N) - F[p]);
+            }
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+enum FinishMode { FIN_SMOOTH_ERR = 0, FIN_MEAN_NN = 1, FIN_RAW = 2 };
+
+// second stage of every norm: fixed-order sum of the per-block partials
+__global__ __launch_bounds__(1024) void k_finish(const double *__restrict__ part, size_t n, int mode, int N,
+                                                 double *__restrict__ out)
+{
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) {
+        double e = s;
+        if (mode == FIN_SMOOTH_ERR) {  // *error = sum1+sum2; *error = *error/N/N  (:621-622)
+            e = s + s;
+            e = e / N / N;
+        } else if (mode == FIN_MEAN_NN) {  // MGerror / (double)(N*N)  (:445)
+            e = s / (double)(N * N);
+        }
+        *out = e;
+    }
+}
+
+// ---------------------------------------------------------------- restriction
+// src/MG_solver_CPU.cpp:656-678 with the 1-D tables built on the host from the
+// reference's floor/fmod expressions (:661-666); rim of the coarse grid is 0 (:651)
+__global__ __launch_bounds__(TB) void k_restrict(int N, const double *__restrict__ Uf, int M,
+                                                 double *__restrict__ Uc, const int *__restrict__ lo,
+                                                 const double *__restrict__ w, int sign)
+{
+    const int cc = blockIdx.x * TB + threadIdx.x;
+    const int rc = blockIdx.y;
+    if (cc >= M) return;
+    double v = 0.0;
+    if (!rim(rc, cc, M)) {
+        const double a = w[cc], b = 1.0 - a;
+        const double c = w[rc], d = 1.0 - c;
+        const size_t f = (size_t)lo[cc] + (size_t)lo[rc] * N;
+        v = b * d * Uf[f] + a * d * Uf[f + 1] + c * b * Uf[f + N] + a * c * Uf[f + N + 1];
+        if (sign < 0) v = -v;
+    }
+    Uc[(size_t)rc * M + cc] = v;
+}
+
+// ---------------------------------------------------------------- prolongation
+// src/MG_solver_CPU.cpp:688-700 turned into a gather over fine points: the owning
+// coarse cell and the four 1-D weight factors come from host tables that replay the
+// reference's ceil() ranges and last-row/column rules (:697-718).
+template <bool ADD>
+__global__ __launch_bounds__(TB) void k_prolong(int N, const double *__restrict__ Uc, int M,
+                                                const double *__restrict__ Uf_in, double *__restrict__ Uf_out,
+                                                const int *__restrict__ orow, const int *__restrict__ ocol,
+                                                const double *__restrict__ row_hi, const double *__restrict__ row_lo,
+                                                const double *__restrict__ col_hi, const double *__restrict__ col_lo,
+                                                double c_dx)
+{
+    const int l = blockIdx.x * TB + threadIdx.x;
+    const int kf = blockIdx.y;
+    if (l >= M) return;
+    const int i = orow[kf], j = ocol[l];
+    const size_t q = (size_t)kf * M + l;
+    if (i < 0 || j < 0) {  // no coarse cell writes this point (never for M >= N)
+        if (ADD) Uf_out[q] = Uf_in[q];
+        return;
+    }
+    const size_t p = (size_t)i * N + j;
+    const double c1 = Uc[p], c2 = Uc[p + 1], c3 = Uc[p + N], c4 = Uc[p + N + 1];
+    const double xh = col_hi[l], xl = col_lo[l], yh = row_hi[kf], yl = row_lo[kf];
+    const double v = ((c1 * xh + c2 * xl) * yh + (c3 * xh + c4 * xl) * yl) / c_dx / c_dx;
+    Uf_out[q] = ADD ? Uf_in[q] + v : v;   // doGridAddition :569: U1 = U1 + U2
+}
+
+// ---------------------------------------------------------------- elementwise
+__global__ __launch_bounds__(TB) void k_add(size_t n, double *__restrict__ a, const double *__restrict__ b)
+{
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) a[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(TB) void k_negate(size_t n, double *__restrict__ a)
+{
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) a[i] = -a[i];
+}
+
+// ---------------------------------------------------------------- problem definition
+// src/MG_solver_CPU.cpp:488 / :544.  Device exp() is within 1 ulp of libm's, so these
+// are NOT bit-identical to the host evaluation; the driver uses the host form for F.
+__global__ __launch_bounds__(TB) void k_source(int N, double h, double *__restrict__ F, double min_x, double min_y)
+{
+    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y;
+    if (c >= N) return;
+    double v = 0.0;
+    if (!rim(r, c, N)) {
+        const double x = (double)c * h + min_x, y = (double)r * h + min_y;
+        v = 2.0 * x * (y - 1) * (y - 2.0 * x + x * y + 2.0) * exp(x - y);
+    }
+    F[(size_t)r * N + c] = v;
+}
+__device__ __forceinline__ double analytic_at(int r, int c, int N, double h, double min_x, double min_y)
+{
+    if (rim(r, c, N)) return 0.0;
+    const double x = (double)c * h + min_x, y = (double)r * h + min_y;
+    return exp(x - y) * x * (1.0 - x) * y * (1.0 - y);
+}
+__global__ __launch_bounds__(TB) void k_analytic(int N, double h, double *__restrict__ U, double min_x, double min_y)
+{
+    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y;
+    if (c >= N) return;
+    U[(size_t)r * N + c] = analytic_at(r, c, N, h, min_x, min_y);
+}
+__global__ __launch_bounds__(TB) void k_analytic_error(int N, double h, const double *__restrict__ U, double min_x,
+                                                       double min_y, double *__restrict__ part)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    const int r0 = blockIdx.y * ROWS_PB;
+    double acc = 0.0;
+    if (c < N) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PB; ++k) {
+            const int r = r0 + k;
+            if (r < N) acc += fabs(analytic_at(r, c, N, h, min_x, min_y) - U[(size_t)r * N + c]);
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------- synthetic data
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z *= 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__global__ __launch_bounds__(TB) void k_fill_uniform(double *__restrict__ dst, size_t n, uint64_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB)
+        dst[i] = (double)(mix64((uint64_t)i + seed) >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ __launch_bounds__(TB) void k_checksum(const double *__restrict__ src, size_t n,
+                                                 unsigned long long *__restrict__ out)
+{
+    unsigned long long s0 = 0, s1 = 0;
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) {
+        const double v = src[i] + 0.0;  // -0.0 -> +0.0
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        s0 += bits;
+        s1 += bits * (2ull * (unsigned long long)i + 1ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o, 64);
+        s1 += __shfl_down(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {  // integer atomics: order-independent, deterministic
+        atomicAdd(&out[0], s0);
+        atomicAdd(&out[1], s1);
+    }
+}
+
+// ---------------------------------------------------------------- Gauss-Seidel
+// src/MG_solver_CPU.cpp:952-1066.  Colour 0 = (row+col) even (the ieven table
+// :973-980), colour 1 = odd (:983-990); update :1020/:1043; err :1051-1059.
+__device__ __forceinline__ double gs_update(const double *U, const double *F, int p, int N, double h2)
+{
+    return 0.25 * (U[p - 1] + U[p + 1] + U[p + N] + U[p - N] - h2 * F[p]);
+}
+
+constexpr int GS_MAX_ITER = 50000000;
+
+// whole solve in ONE workgroup: U (and F when it fits) live in LDS, convergence is
+// tested on the device every iteration exactly like the reference's while loop.
+template <bool F_IN_LDS>
+__global__ __launch_bounds__(1024) void k_gs_workgroup(int N, double h2, double inv, double *__restrict__ Ug,
+                                                       const double *__restrict__ Fg, double tol,
+                                                       int *__restrict__ state)
+{
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double s_err;
+    double *U = lds;
+    const int n = N * N;
+    const double *F = Fg;
+    if (F_IN_LDS) {
+        double *Fl = lds + n;
+        for (int p = threadIdx.x; p < n; p += blockDim.x) Fl[p] = Fg[p];
+        F = Fl;
+    }
+    for (int p = threadIdx.x; p < n; p += blockDim.x) U[p] = 0.0;  // memset(U, 0)  :993
+    __syncthreads();
+
+    const double denom = (double)((N - 2) * (N - 2));
+    int iterations = 0;
+    for (;;) {
+        for (int colour = 0; colour < 2; ++colour) {
+            for (int p = threadIdx.x; p < n; p += blockDim.x) {
+                const int r = p / N, c = p - r * N;
+                if (!rim(r, c, N) && ((r + c) & 1) == colour) U[p] = gs_update(U, F, p, N, h2);
+            }
+            __syncthreads();
+        }
+        ++iterations;
+        double acc = 0.0;
+        for (int p = threadIdx.x; p < n; p += blockDim.x) {
+            const int r = p / N, c = p - r * N;
+            if (!rim(r, c, N))
+                acc = acc + fabs(inv * (U[p + N] + U[p - N] + U[p + 1] + U[p - 1] - 4 * U[p]) - F[p]);
+        }
+        const double s = block_sum(acc);
+        if (threadIdx.x == 0) s_err = s / denom;
+        __syncthreads();
+        const double err = s_err;
+        if (!(err > tol) || iterations >= GS_MAX_ITER) break;  // while (err > target_error)
+    }
+    for (int p = threadIdx.x; p < n; p += blockDim.x) Ug[p] = U[p];
+    if (threadIdx.x == 0) {
+        state[0] = 1;
+        state[1] = iterations;
+    }
+}
+
+// multi-workgroup form for grids that do not fit one CU's LDS: one launch per colour
+// plus a norm; every kernel is a no-op once state[0] (done) is set, so the host may
+// enqueue iterations in batches without changing the result.
+__global__ __launch_bounds__(TB) void k_gs_colour(int N, double h2, double *__restrict__ U,
+                                                  const double *__restrict__ F, int colour,
+                                                  const int *__restrict__ state)
+{
+    if (state[0]) return;
+    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y;
+    if (c >= N || rim(r, c, N) || ((r + c) & 1) != colour) return;
+    const size_t p = (size_t)r * N + c;
+    U[p] = 0.25 * (U[p - 1] + U[p + 1] + U[p + N] + U[p - N] - h2 * F[p]);
+}
+__global__ __launch_bounds__(TB) void k_gs_norm(int N, double inv, const double *__restrict__ U,
+                                                const double *__restrict__ F, double *__restrict__ part,
+                                                const int *__restrict__ state)
+{
+    if (state[0]) return;
+    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y;
+    double acc = 0.0;
+    if (c < N && !rim(r, c, N)) {
+        const size_t p = (size_t)r * N + c;
+        acc = fabs(inv * star_minus4(U, p, N) - F[p]);
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(1024) void k_gs_check(const double *__restrict__ part, size_t n, int N, double tol,
+                                                   int *__restrict__ state)
+{
+    if (state[0]) return;
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) {
+        const double err = s / (double)((N - 2) * (N - 2));
+        state[1] += 1;
+        if (!(err > tol) || state[1] >= GS_MAX_ITER) state[0] = 1;
+    }
+}
+
+inline dim3 grid_rows(int N, int rows_per_block) { return dim3((N + TB - 1) / TB, (N + rows_per_block - 1) / rows_per_block); }
+inline int grid_flat(size_t n)
+{
+    size_t b = (n + TB - 1) / TB;
+    const size_t cap = 256 * 16;
+    return (int)(b < cap ? (b ? b : 1) : cap);
+}
+
+void finish(hipStream_t s, const double *part, size_t n, int mode, int N, double *out)
+{
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, s, part, n, mode, N, out);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out)
+{
+    const dim3 g = grid_rows(N, ROWS_PB);
+    if (in) hipLaunchKernelGGL(k_jacobi_simple<false>, g, dim3(TB), 0, s, N, dx2, in, F, out);
+    else hipLaunchKernelGGL(k_jacobi_simple<true>, g, dim3(TB), 0, s, N, dx2, in, F, out);
+}
+
+void residual(hipStream_t s, int N, double inv, const double *U, const double *F, double *D, int sign)
+{
+    hipLaunchKernelGGL(k_residual, grid_rows(N, ROWS_PB), dim3(TB), 0, s, N, inv, U, F, D, sign);
+}
+
+void smoothing_error(hipStream_t s, int N, double inv, const double *U, const double *F, double *out)
+{
+    const dim3 g = grid_rows(N, ROWS_PB);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    hipLaunchKernelGGL(k_smoothing_error, g, dim3(TB), 0, s, N, inv, U, F, part);
+    finish(s, part, np, FIN_SMOOTH_ERR, N, out);
+}
+
+void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign)
+{
+    hipLaunchKernelGGL(k_restrict, dim3((M + TB - 1) / TB, M), dim3(TB), 0, s, N, Uf, M, Uc, t.lo, t.w, sign);
+}
+
+void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t)
+{
+    const dim3 g((M + TB - 1) / TB, M);
+    if (Uf_in)
+        hipLaunchKernelGGL(k_prolong<true>, g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
+                           t.row_hi, t.row_lo, t.col_hi, t.col_lo, t.c_dx);
+    else
+        hipLaunchKernelGGL(k_prolong<false>, g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
+                           t.row_hi, t.row_lo, t.col_hi, t.col_lo, t.c_dx);
+}
+
+void add(hipStream_t s, size_t n, double *a, const double *b)
+{
+    hipLaunchKernelGGL(k_add, dim3(grid_flat(n)), dim3(TB), 0, s, n, a, b);
+}
+void negate(hipStream_t s, size_t n, double *a)
+{
+    hipLaunchKernelGGL(k_negate, dim3(grid_flat(n)), dim3(TB), 0, s, n, a);
+}
+
+void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y)
+{
+    hipLaunchKernelGGL(k_source, dim3((N + TB - 1) / TB, N), dim3(TB), 0, s, N, L / (double)(N - 1), F, min_x, min_y);
+}
+void analytic(hipStream_t s, int N, double L, double *U, double min_x, double min_y)
+{
+    hipLaunchKernelGGL(k_analytic, dim3((N + TB - 1) / TB, N), dim3(TB), 0, s, N, L / (double)(N - 1), U, min_x, min_y);
+}
+void analytic_error(hipStream_t s, int N, double L, const double *U, double min_x, double min_y, double *out)
+{
+    const dim3 g = grid_rows(N, ROWS_PB);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    hipLaunchKernelGGL(k_analytic_error, g, dim3(TB), 0, s, N, L / (double)(N - 1), U, min_x, min_y, part);
+    finish(s, part, np, FIN_MEAN_NN, N, out);
+}
+
+void fill_uniform(hipStream_t s, double *dst, size_t n, uint64_t seed)
+{
+    hipLaunchKernelGGL(k_fill_uniform, dim3(grid_flat(n)), dim3(TB), 0, s, dst, n, seed);
+}
+void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev)
+{
+    (void)hipMemsetAsync(out_dev, 0, 2 * sizeof(uint64_t), s);
+    hipLaunchKernelGGL(k_checksum, dim3(grid_flat(n)), dim3(TB), 0, s, src, n, (unsigned long long *)out_dev);
+}
+
+int gs_single_workgroup_max_n() { return 128; }
+
+void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol, int *state)
+{
+    (void)hipMemsetAsync(state, 0, 4 * sizeof(int), s);
+    const size_t n = (size_t)N * N;
+    if (N <= gs_single_workgroup_max_n()) {
+        const bool f_in_lds = N <= 96;
+        const size_t lds = n * sizeof(double) * (f_in_lds ? 2 : 1);
+        int threads = (int)((n + 63) / 64 * 64);
+        if (threads > 1024) threads = 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)k_gs_workgroup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute((const void *)k_gs_workgroup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            attr_set = true;
+        }
+        if (f_in_lds) hipLaunchKernelGGL(k_gs_workgroup<true>, dim3(1), dim3(threads), lds, s, N, h2, inv, U, F, tol, state);
+        else hipLaunchKernelGGL(k_gs_workgroup<false>, dim3(1), dim3(threads), lds, s, N, h2, inv, U, F, tol, state);
+        return;
+    }
+    // large coarsest grids: batches of iterations, host polls the done flag
+    (void)hipMemsetAsync(U, 0, n * sizeof(double), s);
+    const dim3 g((N + TB - 1) / TB, N);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    Context &c = ctx();
+    for (;;) {
+        for (int it = 0; it < 32; ++it) {
+            hipLaunchKernelGGL(k_gs_colour, g, dim3(TB), 0, s, N, h2, U, F, 0, state);
+            hipLaunchKernelGGL(k_gs_colour, g, dim3(TB), 0, s, N, h2, U, F, 1, state);
+            hipLaunchKernelGGL(k_gs_norm, g, dim3(TB), 0, s, N, inv, U, F, part, state);
+            hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(1024), 0, s, part, np, N, tol, state);
+        }
+        if (!MG_HIP(hipMemcpyAsync(c.host_ints, state, 2 * sizeof(int), hipMemcpyDeviceToHost, s))) return;
+        if (!MG_HIP(hipStreamSynchronize(s))) return;
+        if (c.host_ints[0]) break;
+    }
+}
+
+}  // namespace k
+}  // namespace mg

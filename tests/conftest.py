@@ -1,0 +1,88 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def bits_equal_mod_zero_sign(a, b):
+    """bit equality after canonicalising -0.0 to +0.0 (folded sign flip)."""
+    return bits_equal(np.asarray(a) + 0.0, np.asarray(b) + 0.0)
+
+
+def assert_bits(a, b, what="", zero_sign=False):
+    ok = bits_equal_mod_zero_sign(a, b) if zero_sign else bits_equal(a, b)
+    if not ok:
+        a = np.asarray(a); b = np.asarray(b)
+        bad = np.argwhere(a.view(np.uint64) != b.view(np.uint64)) if a.shape == b.shape else []
+        diff = np.max(np.abs(a - b)) if a.shape == b.shape else None
+        raise AssertionError(f"{what}: arrays differ bitwise at {len(bad)} points, first {bad[:4].tolist()}, max|diff|={diff}")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import _oracle
+    return _oracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    import _oracle
+    if not _oracle.have_reference():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    return _oracle.Reference()
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    return np.load(os.path.join(GOLDEN, "golden_ops.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_e2e():
+    return np.load(os.path.join(GOLDEN, "golden_e2e.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tables():
+    return np.load(os.path.join(GOLDEN, "golden_tables.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_reports():
+    with open(os.path.join(GOLDEN, "golden_reports.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_fullsize():
+    with open(os.path.join(GOLDEN, "golden_fullsize.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def mg():
+    """The engine, initialised on cuda:0.  Fails (does not skip) when the HIP library or
+    the device is missing: GPU tests must never pass on a fallback."""
+    import multigrid_poisson_solver_amd as m
+    m.init(0)
+    yield m
+    m.finalize()

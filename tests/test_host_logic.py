@@ -1,0 +1,137 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every
+symbol include/mg_hip.h declares, the host-built R/P tables equal the oracle's and the
+committed goldens, the engine refuses to run without a GPU (no CPU fallback), and the
+cycle-file generators reproduce the shipped files.  No compute call is made here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_bits
+
+
+@pytest.fixture(scope="module")
+def m():
+    import multigrid_poisson_solver_amd as m
+    if not os.path.exists(m.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    m.load_library()
+    return m
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(m):
+    import ctypes
+    lib = ctypes.CDLL(m.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"libmgpoisson.so does not export {n}"
+    # and the Python binding table covers the same set
+    assert sorted(m.ABI) == names
+
+
+def test_dropin_header_names_match_reference_surface():
+    """include/mg_dropin.hpp maps the reference's six operator names (plus the problem
+    functions) onto the ABI with identical argument lists (src/MG_solver_CPU.cpp:16-30)."""
+    text = open(os.path.join(ROOT, "include", "mg_dropin.hpp")).read()
+    for proto in ["void getResidual(int N, double L, double* U, double* F, double* D)",
+                  "void doGridAddition(int N, double* U1, double* U2)",
+                  "void doSmoothing(int N, double L, double* U, double* F, int step, double* error)",
+                  "void doExactSolver(int N, double L, double* U, double* F, double target_error, int option)",
+                  "void doRestriction(int N, double* U_f, int M, double* U_c)",
+                  "void doProlongation(int N, double* U_c, int M, double* U_f)"]:
+        assert proto in text, proto
+
+
+def test_no_cpu_fallback_without_gpu(m):
+    """On a machine without a HIP device mg_init must fail loudly and every operator must
+    refuse to run (the product path never routes through a CPU implementation)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    code = ("import multigrid_poisson_solver_amd as m\n"
+            "try:\n    m.init(0)\nexcept m.MGError as e:\n    print('REFUSED', e)\n"
+            "lib = m.load_library(); lib.mg_set_abort_on_error(0)\n"
+            "lib.mg_doSmoothing(16, 1.0, None, None, 1, None)\nprint('ERR', lib.mg_last_error())\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "REFUSED" in out.stdout and "no CPU fallback" in (out.stdout + out.stderr)
+    assert "ERR 4" in out.stdout
+
+
+def test_cli_argument_errors(m):
+    """src/MG_solver_CPU.cpp:51-54: wrong argument count prints the reference's message
+    and exits 1."""
+    out = subprocess.run([m.EXE_PATH], capture_output=True, text=True)
+    assert out.returncode == 1 and "[ ERROR ]: Wrong input numbers of parameter." in out.stdout
+
+
+def test_product_restriction_tables(m, oracle, golden_tables):
+    N = 32768
+    while N // 2 >= 8:
+        M = N // 2
+        lo, w = m.restriction_table(N, M)
+        assert np.array_equal(lo, golden_tables[f"rt_lo_{N}to{M}"])
+        assert_bits(w, golden_tables[f"rt_w_{N}to{M}"], f"restriction weights {N}->{M}")
+        N = M
+    for (N, M) in [(17, 9), (16, 15), (33, 16), (100, 37), (256, 255), (11585, 5792)]:
+        lo, w = m.restriction_table(N, M)
+        olo, ow = oracle.restriction_table(N, M)
+        assert np.array_equal(lo, olo)
+        assert_bits(w, ow, "w")
+
+
+def test_product_prolongation_tables(m, oracle, golden_tables):
+    N = 32768
+    while N // 2 >= 8:
+        M = N // 2
+        for axis in (0, 1):
+            owner, hi, lo = m.prolongation_table(M, N, axis)
+            assert np.array_equal(owner, golden_tables[f"po_{M}to{N}"]), (M, N, axis)
+        N = M
+    for (N, M) in [(15, 16), (9, 17), (16, 33), (4, 8), (37, 100), (5792, 11585)]:
+        want = oracle.prolongation_owner(N, M)
+        for axis in (0, 1):
+            owner, hi, lo = m.prolongation_table(N, M, axis)
+            assert np.array_equal(owner, want)
+            assert owner.min() >= 0 and owner.max() <= N - 2
+            # the two 1-D weights of one fine index sum to the coarse spacing (to rounding)
+            np.testing.assert_allclose(hi + lo, 1.0 / (N - 1), rtol=1e-12)
+
+
+def test_product_prolongation_table_reproduces_oracle_values(m, oracle):
+    """Evaluate the gather formula of the prolongation kernel on the host with the product's
+    tables: it must equal the oracle's (= the reference's) scatter loop bit for bit."""
+    for (N, M) in [(4, 8), (8, 16), (15, 16), (9, 17), (16, 33), (32, 64)]:
+        rng = np.random.default_rng(N * 1000 + M)
+        Uc = rng.random((N, N)) - 0.5
+        orow, rhi, rlo = m.prolongation_table(N, M, 0)
+        ocol, chi, clo = m.prolongation_table(N, M, 1)
+        c_dx = 1.0 / float(N - 1)
+        I, J = np.meshgrid(orow, ocol, indexing="ij")
+        c1, c2, c3, c4 = Uc[I, J], Uc[I, J + 1], Uc[I + 1, J], Uc[I + 1, J + 1]
+        xh, xl = chi[None, :], clo[None, :]
+        yh, yl = rhi[:, None], rlo[:, None]
+        mine = ((c1 * xh + c2 * xl) * yh + (c3 * xh + c4 * xl) * yl) / c_dx / c_dx
+        assert_bits(mine, oracle.doProlongation(N, Uc, M, fill=0.0), f"prolongation tables {N}->{M}")
+
+
+def test_cycle_file_generators(m, tmp_path):
+    v = tmp_path / "v.txt"
+    m.write_vcycle_file(str(v), 256, 8, 3, 1e-7)
+    shipped = open(os.path.join(GOLDEN, "cycles", "Vcycle.txt")).read().split()
+    assert [float(t) for t in v.read_text().split()] == [float(t) for t in shipped]
+    w = tmp_path / "w.txt"
+    m.write_wcycle_file(str(w), 256, 8, 3, 1e-8, depth=4)
+    shipped = open(os.path.join(GOLDEN, "cycles", "Wcycle.txt")).read().split()
+    assert [float(t) for t in w.read_text().split()] == [float(t) for t in shipped]
+    assert m.write_vcycle_file(str(v), 8192, 8) == 11
