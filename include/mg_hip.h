@@ -131,6 +131,21 @@ void mg_fill_uniform(double *dst, size_t n_doubles, uint64_t seed);
 void mg_checksum(const double *src, size_t n_doubles, uint64_t out[2]);
 
 /* ------------------------------------------------------------------------- */
+/* live kernel timing (bench.py's roofline object): hipEvent pairs recorded on   */
+/* the engine's stream around every operator launch on grids with N >= min_N     */
+/* ------------------------------------------------------------------------- */
+typedef struct mg_profile_entry {
+    char   name[40];        /* kernel family, e.g. "jacobi_stream<3>" */
+    int    N;               /* grid size */
+    int    launches;
+    double total_ms;        /* sum of the launches' durations */
+    double algo_bytes;      /* ALGORITHMIC bytes of ONE launch */
+} mg_profile_entry;
+void mg_profile_begin(int min_N);
+/* synchronises, fills out[0..cap) with one entry per (name, N), returns the count */
+int  mg_profile_end(mg_profile_entry *out, int cap);
+
+/* ------------------------------------------------------------------------- */
 /* cycle-file driver: main() of src/MG_solver_CPU.cpp:36-462                   */
 /* ------------------------------------------------------------------------- */
 typedef struct mg_node_record {

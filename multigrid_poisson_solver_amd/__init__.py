@@ -27,6 +27,11 @@ class NodeRecord(C.Structure):
     _fields_ = [("node", C.c_int), ("N", C.c_int), ("steps", C.c_int), ("error", C.c_double)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("N", C.c_int), ("launches", C.c_int), ("total_ms", C.c_double),
+                ("algo_bytes", C.c_double)]
+
+
 class CycleResult(C.Structure):
     _fields_ = [("status", C.c_int), ("N", C.c_int), ("U_dev", C.c_void_p), ("mg_error", C.c_double),
                 ("time_ms", C.c_double), ("device_ms", C.c_double), ("n_records", C.c_int),
@@ -61,6 +66,7 @@ ABI = {
     "mg_cycle_load": (_vp, [C.c_char_p, _i]), "mg_cycle_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_cycle_destroy": (None, [_vp]), "mg_cycle_main": (_i, [_i, C.POINTER(C.c_char_p)]),
     "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
+    "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
 }
 
 _lib = None
@@ -309,6 +315,19 @@ def prolongation_table(N, M, axis):
     lo = np.empty(M)
     load_library().mg_prolongation_table(N, M, axis, owner.ctypes.data, hi.ctypes.data, lo.ctypes.data)
     return owner, hi, lo
+
+
+def profile_begin(min_N=0):
+    lib().mg_profile_begin(int(min_N))
+    _check()
+
+
+def profile_end(cap=256):
+    buf = (ProfileEntry * cap)()
+    n = lib().mg_profile_end(buf, cap)
+    _check()
+    return [dict(name=buf[i].name.decode(), N=buf[i].N, launches=buf[i].launches, total_ms=buf[i].total_ms,
+                 algo_bytes=buf[i].algo_bytes) for i in range(n)]
 
 
 class CyclePlan:

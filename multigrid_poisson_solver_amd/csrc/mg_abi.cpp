@@ -109,6 +109,43 @@ double *partials(size_t n)
     return c.partials;
 }
 
+// ------------------------------------------------------------------ live timing
+static bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+ProfScope::ProfScope(const char *name, int N, double algo_bytes)
+{
+    Context &c = ctx();
+    if (!c.profiling || N < c.profile_min_N || stream_is_capturing(c.stream)) return;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!c.event_pool.empty()) {
+            e[i] = c.event_pool.back();
+            c.event_pool.pop_back();
+        } else if (hipEventCreate(&e[i]) != hipSuccess) {
+            return;
+        }
+    }
+    Context::ProfRec r{name, N, algo_bytes, e[0], e[1]};
+    c.prof.push_back(r);
+    slot = (int)c.prof.size() - 1;
+    (void)hipEventRecord(e[0], c.stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot < 0) return;
+    Context &c = ctx();
+    (void)hipEventRecord(c.prof[slot].e1, c.stream);
+}
+
 namespace {
 
 struct Scalars {  // slots inside ctx().scalars
@@ -180,9 +217,15 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         // start in the partner, the last launch then lands in U_out as well.
         double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
         if (stream) {
+            // algorithmic bytes: 24 B per sweep and point, + 8 for a folded
+            // zero-fill, + 24 for a folded residual; the fused error costs nothing
+            char name[40];
+            snprintf(name, sizeof name, "jacobi_stream<%d%s%s>", take, src ? "" : ",zero", (last && D_out) ? ",res" : "");
+            ProfScope ps(name, N, (double)n * (24.0 * take + (src ? 0.0 : 8.0) + ((last && D_out) ? 24.0 : 0.0)));
             k::jacobi_stream(s, N, dx2, inv, src, F, dst, take, last ? error_dev : nullptr, last ? D_out : nullptr,
                              d_sign, nullptr, 0, nullptr);
         } else {
+            ProfScope ps(src ? "jacobi_simple" : "jacobi_simple<zero>", N, (double)n * (src ? 24.0 : 32.0));
             k::jacobi_simple(s, N, dx2, src, F, dst);
         }
         src = dst;
@@ -190,8 +233,14 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
     }
     if (own_partner) scratch_pool().put(partner);  // stream-ordered: later users queue behind us
     if (!stream) {
-        if (error_dev) k::smoothing_error(s, N, inv, U_out, F, error_dev);
-        if (D_out) k::residual(s, N, inv, U_out, F, D_out, d_sign);
+        if (error_dev) {
+            ProfScope ps("smoothing_error", N, 0.0);
+            k::smoothing_error(s, N, inv, U_out, F, error_dev);
+        }
+        if (D_out) {
+            ProfScope ps("residual", N, (double)n * 24.0);
+            k::residual(s, N, inv, U_out, F, D_out, d_sign);
+        }
     }
 }
 
@@ -262,6 +311,8 @@ void mg_finalize(void)
     (void)hipFree(c.gs_state);
     (void)hipHostFree(c.host_scalars);
     (void)hipHostFree(c.host_ints);
+    for (hipEvent_t e : c.event_pool) (void)hipEventDestroy(e);
+    c.event_pool.clear();
     (void)hipStreamDestroy(c.own_stream);
     c.own_stream = c.stream = nullptr;
     c.ready = false;
@@ -410,6 +461,7 @@ void mg_analyticError(int N, double L, const double *U, double min_x, double min
 void mg_getResidual(int N, double L, double *U, double *F, double *D)
 {
     if (!require_ready("getResidual") || !grid_args_ok("getResidual", N)) return;
+    ProfScope ps("residual", N, (double)N * N * 24.0);
     k::residual(ctx().stream, N, 1.0 / spacing_sq(N, L), U, F, D, +1);
 }
 
@@ -476,6 +528,7 @@ void mg_restrict_signed(int N, const double *U_f, int M, double *U_c, int sign)
     if (!require_ready("doRestriction") || !grid_args_ok("doRestriction", N) || !grid_args_ok("doRestriction", M)) return;
     const RestrictTable &t = restrict_table(N, M);
     if (!t.lo) return;
+    ProfScope ps("restrict", N, 8.0 * N * N + 8.0 * M * M);
     k::restrict_gather(ctx().stream, N, U_f, M, U_c, t, sign < 0 ? -1 : +1);
 }
 
@@ -486,6 +539,7 @@ void mg_doProlongation(int N, double *U_c, int M, double *U_f)
     if (!require_ready("doProlongation") || !grid_args_ok("doProlongation", N) || !grid_args_ok("doProlongation", M)) return;
     const ProlongTable &t = prolong_table(N, M);
     if (!t.owner_row) return;
+    ProfScope ps("prolong", M, 8.0 * N * N + 8.0 * M * M);
     k::prolong(ctx().stream, N, U_c, M, nullptr, U_f, t);
 }
 
@@ -494,7 +548,56 @@ void mg_prolongAdd(int N, const double *U_c, int M, const double *U_f_in, double
     if (!require_ready("mg_prolongAdd") || !grid_args_ok("mg_prolongAdd", N) || !grid_args_ok("mg_prolongAdd", M)) return;
     const ProlongTable &t = prolong_table(N, M);
     if (!t.owner_row) return;
+    ProfScope ps("prolong_add", M, 8.0 * N * N + 16.0 * M * M);
     k::prolong(ctx().stream, N, U_c, M, U_f_in, U_f_out, t);
+}
+
+// ------------------------------------------------------------------ live timing
+void mg_profile_begin(int min_N)
+{
+    if (!require_ready("mg_profile_begin")) return;
+    Context &c = ctx();
+    (void)hipStreamSynchronize(c.stream);
+    for (auto &r : c.prof) {
+        c.event_pool.push_back(r.e0);
+        c.event_pool.push_back(r.e1);
+    }
+    c.prof.clear();
+    c.profile_min_N = min_N;
+    c.profiling = true;
+}
+
+int mg_profile_end(mg_profile_entry *out, int cap)
+{
+    if (!require_ready("mg_profile_end")) return 0;
+    Context &c = ctx();
+    c.profiling = false;
+    (void)hipStreamSynchronize(c.stream);
+    int count = 0;
+    for (auto &r : c.prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+            (void)hipGetLastError();
+            ms = 0.f;
+        }
+        int j = 0;
+        for (; j < count; ++j)
+            if (out[j].N == r.N && r.name == out[j].name) break;
+        if (j == count) {
+            if (count >= cap) continue;
+            memset(&out[j], 0, sizeof out[j]);
+            snprintf(out[j].name, sizeof out[j].name, "%s", r.name.c_str());
+            out[j].N = r.N;
+            out[j].algo_bytes = r.bytes;
+            ++count;
+        }
+        out[j].launches += 1;
+        out[j].total_ms += ms;
+        c.event_pool.push_back(r.e0);
+        c.event_pool.push_back(r.e1);
+    }
+    c.prof.clear();
+    return count;
 }
 
 // ------------------------------------------------------------------ tables

@@ -86,6 +86,19 @@ struct Context {
     int last_error = 0;
     std::string last_error_text;
     bool abort_on_error = true;
+    // profiling (mg_profile_begin/end)
+    bool profiling = false;
+    int profile_min_N = 0;
+    struct ProfRec { std::string name; int N; double bytes; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// live kernel timing: RAII event pair around a launch (no-op unless profiling is on)
+struct ProfScope {
+    ProfScope(const char *name, int N, double algo_bytes);
+    ~ProfScope();
+    int slot = -1;
 };
 
 Context &ctx();
@@ -113,6 +126,8 @@ void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const dou
 void residual(hipStream_t s, int N, double inv, const double *U, const double *F, double *D, int sign);
 // doSmoothing's error: *out = (S+S)/N/N, S = sum over (row+col) even interior of |inv*star-F|
 void smoothing_error(hipStream_t s, int N, double inv, const double *U, const double *F, double *out);
+// second stage of doSmoothing's error: *out = (sum+sum)/N/N over n per-block partials
+void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out);
 // temporally blocked streaming smoother (mg_stream.hip): steps <= stream_max_steps()
 int  stream_max_steps();
 bool stream_supported(int N);

@@ -398,6 +398,11 @@ void finish(hipStream_t s, const double *part, size_t n, int mode, int N, double
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
+void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out)
+{
+    finish(s, part, n, FIN_SMOOTH_ERR, N, out);
+}
+
 void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out)
 {
     const dim3 g = grid_rows(N, ROWS_PB);

@@ -12,6 +12,12 @@ sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(HERE, "golden")
 
+# The oracle is OpenMP code.  A GPU box exposes far more hardware threads than the CPU
+# share a job gets (16 per GPU): an unbounded team spins in every barrier of the tiny
+# coarse-grid loops and a 100 ms solve takes minutes.  Bound the team before libgomp loads.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,0 +1,259 @@
+"""Parity of the HIP operators with the CPU oracle, through the C ABI, on a real MI355X.
+Bar (BASELINE.json north_star): restriction/prolongation indexing bit-exact; here every
+output ARRAY is asserted bit-exact (the kernels keep the reference's evaluation order and
+are built with -ffp-contract=off); scalar norms, whose summation order is unspecified even
+in the reference (OpenMP reduction), are held to 1e-12 relative."""
+import numpy as np
+import pytest
+
+import _synth
+from conftest import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12  # tolerance for scalar norms (reduction order)
+SIZES = [3, 4, 5, 8, 15, 16, 17, 33, 64, 100, 129, 257, 512, 1000]
+SMOOTHERS = ["stream", "simple"]
+
+
+def rand_pair(N, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((N, N)), rng.random((N, N)) - 0.5
+
+
+@pytest.fixture(params=SMOOTHERS)
+def smoother(request, mg):
+    mg.set_smoother(request.param)
+    yield request.param
+    mg.set_smoother("stream")
+
+
+@pytest.mark.parametrize("N", SIZES)
+def test_smoothing_vs_oracle(mg, oracle, smoother, N):
+    U0, F = rand_pair(N, N)
+    Fd = mg.DeviceGrid.from_host(F)
+    for step in (1, 2, 3, 4, 5, 10):
+        U = mg.DeviceGrid.from_host(U0)
+        err = mg.doSmoothing(N, 1.0, U, Fd, step)
+        want, werr = oracle.doSmoothing(N, 1.0, U0, F, step)
+        assert_bits(U.to_host(), want, f"doSmoothing N={N} step={step} ({smoother})")
+        assert err == pytest.approx(werr, rel=REL), (N, step)
+
+
+@pytest.mark.parametrize("N", [16, 64, 257, 1024])
+@pytest.mark.parametrize("L", [1.0, 2.5])
+def test_smoothing_fused_forms(mg, oracle, smoother, N, L):
+    """mg_smooth_pp: zero start (memset folded in), fused error, fused +-residual."""
+    U0, F = rand_pair(N, 7 * N)
+    Fd = mg.DeviceGrid.from_host(F)
+    for step in (1, 3, 6):
+        out, D = mg.DeviceGrid(N), mg.DeviceGrid(N)
+        err = mg.smooth_pp(N, L, None, out, Fd, step, want_error=True, D_out=D, d_sign=-1)
+        want, werr = oracle.doSmoothing(N, L, np.zeros((N, N)), F, step)
+        assert_bits(out.to_host(), want, f"zero-start smoothing N={N} step={step}")
+        assert err == pytest.approx(werr, rel=REL)
+        assert_bits(D.to_host(), -oracle.getResidual(N, L, want, F), "fused -residual")
+        Uin = mg.DeviceGrid.from_host(U0)
+        mg.smooth_pp(N, L, Uin, out, Fd, step, D_out=D, d_sign=+1)
+        want, _ = oracle.doSmoothing(N, L, U0, F, step)
+        assert_bits(out.to_host(), want, "out-of-place smoothing")
+        assert_bits(D.to_host(), oracle.getResidual(N, L, want, F), "fused +residual")
+
+
+@pytest.mark.parametrize("N", SIZES)
+def test_residual_add_negate_vs_oracle(mg, oracle, N):
+    U0, F = rand_pair(N, 3 * N)
+    U, Fd, D = mg.DeviceGrid.from_host(U0), mg.DeviceGrid.from_host(F), mg.DeviceGrid(N)
+    mg.getResidual(N, 1.7, U, Fd, D)
+    want = oracle.getResidual(N, 1.7, U0, F)
+    assert_bits(D.to_host(), want, "getResidual")
+    mg.negate(N, D)
+    assert_bits(D.to_host(), -want, "negate")   # rim becomes -0.0 exactly as in the reference
+    mg.doGridAddition(N, U, Fd)
+    assert_bits(U.to_host(), oracle.doGridAddition(N, U0, F), "doGridAddition")
+
+
+PAIRS_R = [(16, 8), (17, 9), (16, 15), (33, 16), (64, 32), (100, 37), (257, 128), (512, 256), (1000, 500), (1024, 512), (2048, 1024)]
+PAIRS_P = [(4, 8), (8, 16), (15, 16), (9, 17), (16, 33), (32, 64), (37, 100), (128, 257), (256, 512), (500, 1000), (1024, 2048)]
+
+
+@pytest.mark.parametrize("N,M", PAIRS_R)
+def test_restriction_vs_oracle(mg, oracle, N, M):
+    Uf = np.random.default_rng(N + M).random((N, N)) - 0.3
+    d_f, d_c = mg.DeviceGrid.from_host(Uf), mg.DeviceGrid.from_host(np.full((M, M), np.nan))
+    mg.doRestriction(N, d_f, M, d_c)
+    want = oracle.doRestriction(N, Uf, M)
+    assert_bits(d_c.to_host(), want, f"doRestriction {N}->{M}")
+    # the driver's sequence negate-then-restrict, and the folded form
+    mg.restrict_signed(N, d_f, M, d_c, -1)
+    assert_bits(d_c.to_host(), oracle.doRestriction(N, -Uf, M), "restrict(-x) folded", zero_sign=True)
+
+
+@pytest.mark.parametrize("N,M", PAIRS_P)
+def test_prolongation_vs_oracle(mg, oracle, N, M):
+    Uc = np.random.default_rng(N * M).random((N, N)) - 0.3
+    d_c, d_f = mg.DeviceGrid.from_host(Uc), mg.DeviceGrid.from_host(np.zeros((M, M)))
+    mg.doProlongation(N, d_c, M, d_f)
+    want = oracle.doProlongation(N, Uc, M, fill=0.0)
+    assert_bits(d_f.to_host(), want, f"doProlongation {N}->{M}")
+    base = np.random.default_rng(1).random((M, M))
+    d_b, d_o = mg.DeviceGrid.from_host(base), mg.DeviceGrid(M)
+    mg.prolongAdd(N, d_c, M, d_b, d_o)
+    assert_bits(d_o.to_host(), oracle.doGridAddition(M, base, want), "prolong+add fused")
+
+
+@pytest.mark.parametrize("N", [4, 5, 8, 15, 16, 17, 32, 33, 64, 96, 100, 128])
+def test_exact_solver_vs_oracle(mg, oracle, N):
+    F = np.random.default_rng(N).random((N, N)) - 0.5
+    tol = 1e-7 if N <= 33 else 1e-3
+    Fd, U = mg.DeviceGrid.from_host(F), mg.DeviceGrid.from_host(np.full((N, N), 3.0))
+    mg.doExactSolver(N, 1.0, U, Fd, tol, 1)
+    want = oracle.doExactSolver(N, 1.0, F, tol)
+    assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    assert_bits(U.to_host(), want, f"GaussSeidel N={N}")
+
+
+def test_exact_solver_multi_workgroup_path(mg, oracle):
+    N = 160  # above the single-workgroup LDS limit
+    F = np.random.default_rng(5).random((N, N)) - 0.5
+    Fd, U = mg.DeviceGrid.from_host(F), mg.DeviceGrid(N)
+    mg.doExactSolver(N, 1.0, U, Fd, 5e-3, 1)
+    want = oracle.doExactSolver(N, 1.0, F, 5e-3)
+    assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    assert_bits(U.to_host(), want, "GaussSeidel multi-workgroup")
+
+
+def test_exact_solver_option0_refused(mg):
+    """src/MG_solver_GPU.cu:1286-1289: the GPU build refuses the inverse-matrix solver."""
+    U, F = mg.DeviceGrid.zeros(8), mg.DeviceGrid.zeros(8)
+    with pytest.raises(mg.MGError, match="Inverse Matrix"):
+        mg.doExactSolver(8, 1.0, U, F, 1e-7, 0)
+
+
+def test_problem_definition(mg, oracle):
+    for N in (16, 129):
+        F = mg.getSource(N, 1.5, 0.25, -0.5)
+        assert_bits(F.to_host(), oracle.getSource(N, 1.5, 0.25, -0.5), "getSource (host libm form)")
+        A = mg.getAnalytic(N).to_host()
+        np.testing.assert_allclose(A, oracle.getAnalytic(N), rtol=2e-15, atol=0)  # device exp: a few ulp after the products
+        U = np.random.default_rng(N).random((N, N))
+        got = mg.analyticError(N, 1.0, mg.DeviceGrid.from_host(U))
+        want = np.abs(oracle.getAnalytic(N) - U).sum() / (N * N)
+        assert got == pytest.approx(want, rel=1e-12)
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("N", [16, 64])
+def test_golden_ops(mg, golden_ops, N):
+    g = golden_ops
+    for tag, U0, F in (("src", np.zeros((N, N)), g[f"N{N}_F_source"]), ("rnd", g[f"N{N}_U_rand"], g[f"N{N}_F_rand"])):
+        Fd = mg.DeviceGrid.from_host(F)
+        for s in (1, 3, 10):
+            U = mg.DeviceGrid.from_host(U0)
+            e = mg.doSmoothing(N, 1.0, U, Fd, s)
+            assert_bits(U.to_host(), g[f"N{N}_{tag}_smooth{s}_U"], f"golden smoothing {tag} {s}")
+            assert e == pytest.approx(g[f"N{N}_{tag}_smooth{s}_err"][0], rel=REL)
+        U3 = mg.DeviceGrid.from_host(g[f"N{N}_{tag}_smooth3_U"])
+        D = mg.DeviceGrid(N)
+        mg.getResidual(N, 1.0, U3, Fd, D)
+        assert_bits(D.to_host(), g[f"N{N}_{tag}_residual"], "golden residual")
+        mg.negate(N, D)
+        C = mg.DeviceGrid(N // 2)
+        mg.doRestriction(N, D, N // 2, C)
+        assert_bits(C.to_host(), g[f"N{N}_{tag}_restrict_negD"], "golden restrict(-D)")
+        half = mg.DeviceGrid.from_host(g[f"N{N}_{tag}_smooth3_U"][: N // 2, : N // 2].copy())
+        P = mg.DeviceGrid(N)
+        mg.doProlongation(N // 2, half, N, P)
+        assert_bits(P.to_host(), g[f"N{N}_{tag}_prolong_from_half"], "golden prolong")
+        mg.doGridAddition(N, U3, Fd)
+        assert_bits(U3.to_host(), g[f"N{N}_{tag}_add"], "golden add")
+
+
+def test_golden_odd_pairs_kats_and_gs(mg, golden_ops):
+    g = golden_ops
+    for (Nf, Mc) in ((17, 9), (16, 15), (33, 16)):
+        out = mg.DeviceGrid(Mc)
+        mg.doRestriction(Nf, mg.DeviceGrid.from_host(g[f"restrict_{Nf}to{Mc}_in"]), Mc, out)
+        assert_bits(out.to_host(), g[f"restrict_{Nf}to{Mc}_out"], f"golden restrict {Nf}->{Mc}")
+    for (Nc, Mf) in ((15, 16), (9, 17), (16, 33)):
+        out = mg.DeviceGrid.zeros(Mf)
+        mg.doProlongation(Nc, mg.DeviceGrid.from_host(g[f"prolong_{Nc}to{Mf}_in"]), Mf, out)
+        assert_bits(out.to_host(), g[f"prolong_{Nc}to{Mf}_out"], f"golden prolong {Nc}->{Mf}")
+    # the reference's own analytic KATs (testFunction/Test_doRestriction_GPU.cu:189-193,
+    # testFunction/Test_doProlongation_GPU.cu:190-194)
+    out = mg.DeviceGrid(8)
+    mg.doRestriction(16, mg.DeviceGrid.from_host(np.add.outer(np.arange(16.0), np.arange(16.0))), 8, out)
+    assert_bits(out.to_host(), g["kat_restrict_16to8"], "KAT restrict")
+    out = mg.DeviceGrid.zeros(8)
+    mg.doProlongation(4, mg.DeviceGrid.from_host(np.add.outer(np.arange(4.0), np.arange(4.0))), 8, out)
+    assert_bits(out.to_host(), g["kat_prolong_4to8"], "KAT prolong")
+    for N in (8, 16, 17):
+        U = mg.DeviceGrid(N)
+        mg.doExactSolver(N, 1.0, U, mg.DeviceGrid.from_host(g[f"gs_N{N}_F"]), 1e-7, 1)
+        assert_bits(U.to_host(), g[f"gs_N{N}_U"], f"golden GaussSeidel {N}")
+
+
+# ------------------------------------------------------------------ synthetic data
+def test_synthetic_fill_and_checksum(mg):
+    for N, seed in ((64, 11), (257, 22)):
+        g = mg.DeviceGrid.uniform(N, seed)
+        host = _synth.hash_field(N, seed)
+        assert_bits(g.to_host(), host, "mg_fill_uniform")
+        assert g.checksum() == _synth.checksum(host)
+    z = mg.DeviceGrid.from_host(np.array([[0.0, -0.0], [1.5, -2.25]]))
+    assert z.checksum() == _synth.checksum(np.array([[0.0, 0.0], [1.5, -2.25]]))
+
+
+# ------------------------------------------------------------------ full benchmark sizes
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_fullsize_smoothing_and_residual_checksums(mg, golden_fullsize, smoother, N):
+    """BASELINE.json sizes: inputs are hash-generated on the device, the outputs' 128-bit
+    checksums must equal those of the REFERENCE's doSmoothing/getResidual on the same
+    inputs (tests/golden/make_golden.py --big)."""
+    U, F, D = mg.DeviceGrid.uniform(N, 11), mg.DeviceGrid.uniform(N, 22), mg.DeviceGrid(N)
+    mg.getResidual(N, 1.0, U, F, D)
+    assert list(D.checksum()) == golden_fullsize[f"residual_N{N}"]["checksum"]
+    err = mg.doSmoothing(N, 1.0, U, F, 3)
+    assert list(U.checksum()) == golden_fullsize[f"smooth3_N{N}"]["checksum"]
+    assert err == pytest.approx(golden_fullsize[f"smooth3_N{N}"]["error"], rel=REL)
+
+
+@pytest.mark.parametrize("N", [8192, 16384, 32768])
+def test_fullsize_transfer_checksums(mg, golden_fullsize, N):
+    """Bit-exact R/P indexing at 8192 .. 32768 against the reference itself."""
+    M = N // 2
+    Uf, Uc = mg.DeviceGrid.uniform(N, 33), mg.DeviceGrid(M)
+    mg.doRestriction(N, Uf, M, Uc)
+    assert list(Uc.checksum()) == golden_fullsize[f"restrict_{N}to{M}"]["checksum"]
+    Uc.free()
+    src = mg.DeviceGrid.uniform(M, 44)
+    mg.lib().mg_fill_zero(Uf.ptr, Uf.size)
+    mg.doProlongation(M, src, N, Uf)
+    assert list(Uf.checksum()) == golden_fullsize[f"prolong_{M}to{N}"]["checksum"]
+    Uf.free(); src.free()
+    mg.lib().mg_pool_trim()
+
+
+@pytest.mark.parametrize("N", [8192])
+def test_fullsize_properties(mg, smoother, N):
+    """Size-independent properties at the headline size."""
+    F0 = mg.DeviceGrid.zeros(N)
+    # a constant field is a fixed point of the sweep when F = 0 (U + 0.25*(4U - 4U - 0))
+    U = mg.DeviceGrid.from_host(np.full((N, N), 0.625))
+    c0 = U.checksum()
+    mg.doSmoothing(N, 1.0, U, F0, 3, want_error=False)
+    assert U.checksum() == c0
+    # 6 sweeps == 3 + 3 sweeps; zero start == explicit zeros
+    F = mg.DeviceGrid.uniform(N, 5)
+    A, B = mg.DeviceGrid.uniform(N, 6), mg.DeviceGrid.uniform(N, 6)
+    mg.doSmoothing(N, 1.0, A, F, 6, want_error=False)
+    mg.doSmoothing(N, 1.0, B, F, 3, want_error=False)
+    mg.doSmoothing(N, 1.0, B, F, 3, want_error=False)
+    assert A.checksum() == B.checksum()
+    Z, O = mg.DeviceGrid.zeros(N), mg.DeviceGrid(N)
+    mg.doSmoothing(N, 1.0, Z, F, 3, want_error=False)
+    mg.smooth_pp(N, 1.0, None, O, F, 3)
+    assert Z.checksum() == O.checksum()
+    for g in (F0, U, F, A, B, Z, O):
+        g.free()
+    mg.lib().mg_pool_trim()
