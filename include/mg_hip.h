@@ -104,6 +104,13 @@ void mg_doProlongation(int N, double *U_c, int M, double *U_f);
  * sign flip :277-280 folded in). */
 void mg_smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step,
                   double *error_dev, double *D_out, int d_sign);
+/* one "-1" node of the driver (:259-287): U_out = smooth^step(U_in or 0), then
+ * F_c = doRestriction(N, -getResidual(U_out), M) -- one pass over HBM when fusable */
+void mg_smooth_restrict(int N, double L, const double *U_in, double *U_out, double *F, int step,
+                        double *error_dev, int M, double *F_c);
+/* one "1" node of the driver (:353-416): U_out = smooth^step(U_in + doProlongation(Nc, U_c, N)) */
+void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double *U_in, double *U_out,
+                       double *F, int step, double *error_dev);
 /* U_f_out = U_f_in + doProlongation(N, U_c, M) in one pass (:354 + :368) */
 void mg_prolongAdd(int N, const double *U_c, int M, const double *U_f_in, double *U_f_out);
 /* doRestriction(N, sign*U_f, M, U_c) */
@@ -172,6 +179,7 @@ typedef struct mg_cycle_plan mg_cycle_plan;
 #define MG_CYCLE_FUSED   1 /* use the fused operators (default driver mode) */
 #define MG_CYCLE_GRAPH   2 /* capture the node program into a hipGraph and replay it */
 #define MG_CYCLE_REPORT  4 /* build the printed report text */
+#define MG_CYCLE_ERROR   8 /* evaluate mg_error (:434-445) after the window, as the program does */
 
 /* parse a cycle structure file (README.md:43-128); allocates the finest level and
  * evaluates getSource on it (:149-153, outside the timed window) */

@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libmgpoisson.so")
 EXE_PATH = os.path.join(_PKG, "bin", "MG_HIP")
 
-MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT = 1, 2, 4
+MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT, MG_CYCLE_ERROR = 1, 2, 4, 8
 
 
 class MGError(RuntimeError):
@@ -58,6 +58,8 @@ ABI = {
     "mg_doExactSolver": (None, [_i, _d, _vp, _vp, _d, _i]),
     "mg_doRestriction": (None, [_i, _vp, _i, _vp]), "mg_doProlongation": (None, [_i, _vp, _i, _vp]),
     "mg_smooth_pp": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i]),
+    "mg_smooth_restrict": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "mg_prolong_smooth": (None, [_i, _vp, _i, _d, _vp, _vp, _vp, _i, _vp]),
     "mg_prolongAdd": (None, [_i, _vp, _i, _vp, _vp]), "mg_restrict_signed": (None, [_i, _vp, _i, _vp, _i]),
     "mg_lastExactSolverIterations": (_i, []),
     "mg_restriction_table": (None, [_i, _i, _vp, _vp]),
@@ -292,6 +294,27 @@ def smooth_pp(N, L, U_in, U_out, F, step, want_error=False, D_out=None, d_sign=1
     return None
 
 
+def smooth_restrict(N, L, U_in, U_out, F, step, M, F_c, want_error=False):
+    err = DeviceGrid((1,)) if want_error else None
+    lib().mg_smooth_restrict(N, L, U_in.ptr if U_in is not None else None, U_out.ptr, F.ptr, step,
+                             err.ptr if err else None, M, F_c.ptr)
+    _check()
+    if want_error:
+        v = float(err.to_host()[0])
+        err.free()
+        return v
+
+
+def prolong_smooth(Nc, U_c, N, L, U_in, U_out, F, step, want_error=False):
+    err = DeviceGrid((1,)) if want_error else None
+    lib().mg_prolong_smooth(Nc, U_c.ptr, N, L, U_in.ptr, U_out.ptr, F.ptr, step, err.ptr if err else None)
+    _check()
+    if want_error:
+        v = float(err.to_host()[0])
+        err.free()
+        return v
+
+
 def prolongAdd(N, U_c, M, U_f_in, U_f_out):
     lib().mg_prolongAdd(N, U_c.ptr, M, U_f_in.ptr, U_f_out.ptr)
     _check()
@@ -334,8 +357,12 @@ class CyclePlan:
     """mg_cycle_load / mg_cycle_execute: the reference program's timed window
     (src/MG_solver_CPU.cpp:156..429) over a cycle structure file."""
 
-    def __init__(self, path, fused=True, graph=False, report=True):
-        flags = (MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) | (MG_CYCLE_REPORT if report else 0)
+    def __init__(self, path, fused=True, graph=False, report=True, error=True):
+        flags = ((MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) |
+                 (MG_CYCLE_REPORT if report else 0) | (MG_CYCLE_ERROR if error else 0))
+        with open(path) as f:
+            head = f.read().split()[:3]
+        self.L, self.min_x, self.min_y = (float(t) for t in head)
         self._plan = lib().mg_cycle_load(os.fsencode(path), flags)
         _check()
         if not self._plan:
@@ -354,6 +381,13 @@ class CyclePlan:
             _lib.mg_download(U.ctypes.data, res.U_dev, U.size)
             out["U"] = U
         return out
+
+    def analytic_error(self, result):
+        """sum|analytic - U|/N^2 of a finished execute (src/MG_solver_CPU.cpp:434-445)."""
+        e = C.c_double()
+        _lib.mg_analyticError(result["N"], self.L, result["U_ptr"], self.min_x, self.min_y, C.byref(e))
+        _check()
+        return e.value
 
     def close(self):
         if self._plan and _initialised:

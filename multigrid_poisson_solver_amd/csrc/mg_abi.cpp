@@ -175,8 +175,19 @@ inline double spacing_sq(int N, double L)
     return dx * dx;
 }
 
+// fused transfer stages (streaming smoother only): level 0 = U_in + P(coarse) for the first
+// launch, restriction of the signed residual into Fc for the last launch
+struct Fusion {
+    const double *coarse = nullptr;
+    int Nc = 0;
+    const ProlongTable *pt = nullptr;
+    double *Fc = nullptr;
+    int M = 0;
+    const RestrictTable *rt = nullptr;
+};
+
 void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step, double *error_dev,
-               double *D_out, int d_sign)
+               double *D_out, int d_sign, const Fusion &fu = Fusion())
 {
     Context &c = ctx();
     hipStream_t s = c.stream;
@@ -218,12 +229,18 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
         if (stream) {
             // algorithmic bytes: 24 B per sweep and point, + 8 for a folded
-            // zero-fill, + 24 for a folded residual; the fused error costs nothing
+            // zero-fill, + 24 for a folded residual, + 8n + 8m for a folded restriction,
+            // + 8m + 16n for a folded prolongation+addition; the fused error costs nothing
+            const bool pro = (i == 0 && fu.coarse), res = last && (D_out || fu.Fc), rst = last && fu.Fc;
             char name[40];
-            snprintf(name, sizeof name, "jacobi_stream<%d%s%s>", take, src ? "" : ",zero", (last && D_out) ? ",res" : "");
-            ProfScope ps(name, N, (double)n * (24.0 * take + (src ? 0.0 : 8.0) + ((last && D_out) ? 24.0 : 0.0)));
+            snprintf(name, sizeof name, "jacobi_stream<%d%s%s%s%s>", take, src ? "" : ",zero", pro ? ",prolong" : "",
+                     res ? ",res" : "", rst ? ",restrict" : "");
+            double bytes = (double)n * (24.0 * take + (src ? 0.0 : 8.0) + (res ? 24.0 : 0.0));
+            if (rst) bytes += 8.0 * n + 8.0 * fu.M * fu.M;
+            if (pro) bytes += 16.0 * n + 8.0 * fu.Nc * fu.Nc;
+            ProfScope ps(name, N, bytes);
             k::jacobi_stream(s, N, dx2, inv, src, F, dst, take, last ? error_dev : nullptr, last ? D_out : nullptr,
-                             d_sign, nullptr, 0, nullptr);
+                             d_sign, pro ? fu.coarse : nullptr, fu.Nc, fu.pt, rst ? fu.Fc : nullptr, fu.M, fu.rt);
         } else {
             ProfScope ps(src ? "jacobi_simple" : "jacobi_simple<zero>", N, (double)n * (src ? 24.0 : 32.0));
             k::jacobi_simple(s, N, dx2, src, F, dst);
@@ -290,6 +307,7 @@ void mg_finalize(void)
     for (auto &kv : c.rtab) {
         (void)hipFree(kv.second.lo);
         (void)hipFree(kv.second.w);
+        (void)hipFree(kv.second.inv);
     }
     for (auto &kv : c.ptab) {
         (void)hipFree(kv.second.owner_row);
@@ -480,6 +498,79 @@ void mg_smooth_pp(int N, double L, const double *U_in, double *U_out, double *F,
         return;
     }
     smooth_pp(N, L, U_in, U_out, F, step, error_dev, D_out, d_sign < 0 ? -1 : +1);
+}
+
+// pre-smoothing + getResidual + sign flip + doRestriction of one "-1" node
+// (src/MG_solver_CPU.cpp:259-287) in one pass when the streaming kernel can fuse it
+void mg_smooth_restrict(int N, double L, const double *U_in, double *U_out, double *F, int step, double *error_dev,
+                        int M, double *F_c)
+{
+    if (!require_ready("mg_smooth_restrict") || !grid_args_ok("mg_smooth_restrict", N) ||
+        !grid_args_ok("mg_smooth_restrict", M))
+        return;
+    if (U_in == U_out) {
+        fail(MG_ERR_ARG, "mg_smooth_restrict: U_out must differ from U_in");
+        return;
+    }
+    Context &c = ctx();
+    const RestrictTable &rt = restrict_table(N, M);
+    if (!rt.lo) return;
+    if (step > 0 && c.smoother == SMOOTHER_STREAM && k::stream_fusable(N) && rt.fusable) {
+        Fusion fu;
+        fu.Fc = F_c;
+        fu.M = M;
+        fu.rt = &rt;
+        smooth_pp(N, L, U_in, U_out, F, step, error_dev, nullptr, -1, fu);
+        return;
+    }
+    // operator by operator, D in pool scratch
+    const size_t n = (size_t)N * N;
+    double *D = (double *)scratch_pool().get(n * sizeof(double));
+    if (!D) return;
+    smooth_pp(N, L, U_in, U_out, F, step, error_dev, D, -1);
+    {
+        ProfScope ps("restrict", N, 8.0 * N * N + 8.0 * M * M);
+        k::restrict_gather(c.stream, N, D, M, F_c, rt, +1);
+    }
+    scratch_pool().put(D);
+}
+
+// doProlongation + doGridAddition + post-smoothing of one "1" node
+// (src/MG_solver_CPU.cpp:353-416): U_out = smooth^step(U_in + P(U_c))
+void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double *U_in, double *U_out, double *F,
+                       int step, double *error_dev)
+{
+    if (!require_ready("mg_prolong_smooth") || !grid_args_ok("mg_prolong_smooth", N) ||
+        !grid_args_ok("mg_prolong_smooth", Nc))
+        return;
+    if (U_in == U_out) {
+        fail(MG_ERR_ARG, "mg_prolong_smooth: U_out must differ from U_in");
+        return;
+    }
+    Context &c = ctx();
+    const ProlongTable &pt = prolong_table(Nc, N);
+    if (!pt.owner_row) return;
+    if (step > 0 && c.smoother == SMOOTHER_STREAM && k::stream_fusable(N) && pt.fusable) {
+        Fusion fu;
+        fu.coarse = U_c;
+        fu.Nc = Nc;
+        fu.pt = &pt;
+        smooth_pp(N, L, U_in, U_out, F, step, error_dev, nullptr, +1, fu);
+        return;
+    }
+    {
+        ProfScope ps("prolong_add", N, 8.0 * Nc * Nc + 16.0 * N * N);
+        k::prolong(c.stream, Nc, U_c, N, U_in, U_out, pt);
+    }
+    if (step > 0) {
+        // U_out now holds U + P; sweep it through U_in (clobbered) and back
+        const size_t n = (size_t)N * N;
+        double *tmp = (double *)scratch_pool().get(n * sizeof(double));
+        if (!tmp) return;
+        smooth_pp(N, L, U_out, tmp, F, step, error_dev, nullptr, +1);
+        MG_HIP(hipMemcpyAsync(U_out, tmp, n * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+        scratch_pool().put(tmp);
+    }
 }
 
 void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *error)

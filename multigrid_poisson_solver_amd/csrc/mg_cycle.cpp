@@ -289,14 +289,31 @@ void run_nodes(Exec &x)
                 mg_upload(error_slot(p, rec), &lv->smoothingError, 1);
                 mg_getResidual(lv->N, p->L, lv->U, lv->F, lv->D);  // :239
                 mg_negate(lv->N, lv->D);                           // :277-280
+                report_smoothing(p, rec);
+                cycle.Push_back(next_N);                                        // :283
+                mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);  // :287
+            } else if (fused) {
+                // smoothing (:259), residual (:268), sign flip (:277-280) and restriction (:287)
+                // in one pass; the zero fill of U (:256) is folded into the first sweep
+                rec = add_record(p, -1, lv->N, step);
+                report_smoothing(p, rec);
+                cycle.Push_back(next_N);  // :283
+                double *Fc = cycle.last()->F;
+                if (!keep) {
+                    mg_smooth_restrict(lv->N, p->L, nullptr, lv->U, lv->F, step, error_slot(p, rec), next_N, Fc);
+                } else {
+                    double *tmp = (double *)p->pool.get((size_t)lv->N * lv->N * sizeof(double));
+                    mg_smooth_restrict(lv->N, p->L, lv->U, tmp, lv->F, step, error_slot(p, rec), next_N, Fc);
+                    std::swap(lv->U, tmp);
+                    p->pool.put(tmp);
+                }
             } else {
                 rec = add_record(p, -1, lv->N, step);
                 smooth_level(x, lv, step, !keep, true, rec);
+                report_smoothing(p, rec);
+                cycle.Push_back(next_N);                                        // :283
+                mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);  // :287
             }
-            report_smoothing(p, rec);
-
-            cycle.Push_back(next_N);                                            // :283
-            mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);      // :287
             report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
         } else if (node == 0) {  // :305-324
             double tol;
@@ -325,9 +342,20 @@ void run_nodes(Exec &x)
 
             LevelNode *coarse = cycle.last();
             LevelNode *fine = coarse->prevNode;
+            const char *arrow = "             *\n             |\nProlongation |\n             |\n             *\n";
+            if (fused && step > 0) {
+                // tempU (:353), doProlongation (:354), doGridAddition (:368) and the post-smoothing
+                // (:416) in one pass; the fine level's D is dead here and receives the result
+                const int rec = add_record(p, 1, fine->N, step);
+                mg_prolong_smooth(coarse->N, coarse->U, fine->N, p->L, fine->U, fine->D, fine->F, step,
+                                  error_slot(p, rec));
+                std::swap(fine->U, fine->D);
+                cycle.Remove_back();  // :363
+                report_text(p, arrow);
+                report_smoothing(p, rec);
+                continue;
+            }
             if (fused) {
-                // tempU (:353), doProlongation (:354) and doGridAddition (:368) in one pass;
-                // the fine level's D is dead here and serves as the output buffer
                 mg_prolongAdd(coarse->N, coarse->U, fine->N, fine->U, fine->D);
                 std::swap(fine->U, fine->D);
                 cycle.Remove_back();  // :363
@@ -339,7 +367,7 @@ void run_nodes(Exec &x)
                 mg_doGridAddition(fine->N, fine->U, tempU);                   // :368
                 p->pool.put(tempU);                                           // :371
             }
-            report_text(p, "             *\n             |\nProlongation |\n             |\n             *\n");
+            report_text(p, arrow);
 
             if (step == 0) continue;  // :409-411
             LevelNode *lv = cycle.last();
@@ -507,8 +535,9 @@ int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
             if (p->records[i].node != 0) p->records[i].error = all[i];
     }
 
-    double mg_error = 0.0;
-    mg_analyticError(p->final_N, p->L, p->final_U, p->min_x, p->min_y, &mg_error);  // :434-445
+    double mg_error = 0.0;  // outside the reference's timed window as well (:434-445)
+    if (p->flags & (MG_CYCLE_ERROR | MG_CYCLE_REPORT))
+        mg_analyticError(p->final_N, p->L, p->final_U, p->min_x, p->min_y, &mg_error);
 
     if (p->flags & MG_CYCLE_REPORT) {
         Text t;
@@ -586,7 +615,7 @@ int mg_cycle_main(int argc, char **argv)
     printf("Cycle structure file name = %s\n", argv[2]);  // :63
     const char *dev = getenv("MG_DEVICE");
     if (mg_init(dev ? atoi(dev) : 0) != 0) return 1;
-    mg_cycle_plan *plan = mg_cycle_load(argv[2], MG_CYCLE_FUSED | MG_CYCLE_REPORT);
+    mg_cycle_plan *plan = mg_cycle_load(argv[2], MG_CYCLE_FUSED | MG_CYCLE_REPORT | MG_CYCLE_ERROR);
     if (!plan) {
         printf("[ ERROR ]: Cannot open file %s\n", argv[2]);  // :66
         return 1;

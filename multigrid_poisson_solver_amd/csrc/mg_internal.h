@@ -39,12 +39,15 @@ bool hip_ok(hipError_t e, const char *what, const char *file, int line);
 struct RestrictTable {
     int *lo = nullptr;     // [M] lower-left fine index
     double *w = nullptr;   // [M] weight a (resp. c)
+    int *inv = nullptr;    // [N] fine index -> interior coarse index with lo[] == it, else -1
+    bool fusable = false;  // lo[] strictly increasing by >= 2: one coarse sample per column pair
 };
 struct ProlongTable {
     int *owner_row = nullptr, *owner_col = nullptr;        // [M]
     double *row_hi = nullptr, *row_lo = nullptr;           // [M] (c3y - f_y), (f_y - c1y)
     double *col_hi = nullptr, *col_lo = nullptr;           // [M] (c2x - f_x), (f_x - c1x)
     double c_dx = 0.0;
+    bool fusable = false;  // every fine index owned, owners advance by <= 1 per fine index
 };
 
 // ---------------------------------------------------------------------------
@@ -131,9 +134,13 @@ void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, 
 // temporally blocked streaming smoother (mg_stream.hip): steps <= stream_max_steps()
 int  stream_max_steps();
 bool stream_supported(int N);
+bool stream_fusable(int N);   // the fused prolongation / restriction stages exist for this N
+// coarse != nullptr: level 0 is in + doProlongation(coarse) (tables pt).  Fc != nullptr: the
+// d_sign-ed residual of the result is restricted into Fc (M x M, tables rt).
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F,
                    double *out, int steps, double *err_out, double *D_out, int d_sign,
-                   const double *coarse, int Nc, const ProlongTable *pt);
+                   const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
+                   const RestrictTable *rt);
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);

@@ -21,6 +21,17 @@
 //   * the next PF rows are always in flight (register FIFO, loop unrolled by PF) so a
 //     wave keeps 2*PF KiB of loads outstanding without relying on occupancy.
 //
+// Two more stages can be fused into the same pass (COLS = 2 builds):
+//   * IN_PROLONG: level 0 of a row is U_in + doProlongation(coarse) (:354 + :368),
+//     evaluated while the row streams in (coarse rows are cached in registers and
+//     rotate as the owner row advances; 1-D weights come from the host tables);
+//   * RESTRICT: the signed residual rows are restricted on the fly into the next
+//     level's F (:287) -- the lane whose column pair holds lo[cc] combines its pair (or
+//     its right neighbour's, via one DPP shift) of two consecutive residual rows; the
+//     residual D itself then never touches HBM.
+// With both, a V-cycle level costs  F + U + F_coarse (18 B/point) on the way down and
+// U + coarse + F + U (26 B/point) on the way up.
+//
 // Every point is updated with exactly the reference's expression and association order
 // (-ffp-contract=off), so the result is bit-identical to S separate sweeps; a halo point
 // computed twice gets the same bits twice.  Algorithmic traffic of S sweeps + residual:
@@ -38,20 +49,33 @@ constexpr int PF = 4;            // rows of U and F in flight per lane
 constexpr int WAVES_PER_WG = 4;  // 4 adjacent strips of one chunk
 constexpr int MAX_S = 4;
 
+enum InMode { IN_LOAD = 0, IN_ZERO = 1, IN_PROLONG = 2 };
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 struct StreamParams {
     int N;
     double dx2, inv;
-    const double *in;   // nullptr: level 0 is all zero
+    const double *in;   // IN_ZERO: unused
     const double *F;
     double *out;
-    double *D;          // nullptr: no residual output
+    double *D;          // nullptr: residual not stored
     int d_sign;
     double *part;       // nullptr: no error norm; else one partial per wave
     int rows_per_chunk;
     int groups;         // workgroups per chunk row
     int n_blocks;       // chunks * groups
+    // IN_PROLONG: coarse grid and the host-built tables of doProlongation
+    const double *coarse;
+    int Nc;
+    const int *p_orow, *p_ocol;
+    const double *p_rhi, *p_rlo, *p_chi, *p_clo;
+    double c_dx;
+    // RESTRICT: next level's F and the host-built tables of doRestriction
+    double *Fc;
+    int M;
+    const int *r_inv;   // [N] fine index -> coarse index whose lower-left sample it is, or -1
+    const double *r_w;  // [M]
 };
 
 // value of the neighbouring lane (lane-1 / lane+1); lanes at the wave edge read 0
@@ -108,16 +132,38 @@ __device__ __forceinline__ void store_row(double *__restrict__ base, const Row<C
     }
 }
 
-template <int S>
+// halo columns per side: level S must be valid one column beyond the owned strip for the
+// residual stage, two for the fused restriction (it reads the residual one column and one
+// row beyond the owned tile); rounded up to even so strips stay 16 B aligned
+template <int S, bool RESTRICT>
 struct Halo {
-    static constexpr int value = (S + 2) & ~1;  // >= S+1, even (16 B aligned strips)
+    static constexpr int value = (S + (RESTRICT ? 2 : 1) + 1) & ~1;
 };
 
-template <int S, int COLS, bool ZERO_IN>
+// three consecutive coarse values of one coarse row, starting at this lane's base column
+struct Coarse3 {
+    double v[3];
+};
+__device__ __forceinline__ Coarse3 load_coarse(const double *__restrict__ coarse, int Nc, int row, int col, bool ok)
+{
+    Coarse3 c;
+    c.v[0] = c.v[1] = c.v[2] = 0.0;
+    if (ok) {
+        const int r = row < Nc - 1 ? row : Nc - 1;
+        const double *b = coarse + (size_t)r * Nc;
+        c.v[0] = b[col];
+        c.v[1] = b[col + 1 < Nc ? col + 1 : Nc - 1];
+        c.v[2] = b[col + 2 < Nc ? col + 2 : Nc - 1];
+    }
+    return c;
+}
+
+template <int S, int COLS, int IN, bool RESTRICT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
+    static_assert(COLS == 2 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
     constexpr int W = 64 * COLS;
-    constexpr int H = Halo<S>::value;
+    constexpr int H = Halo<S, RESTRICT>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
 
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
@@ -153,7 +199,43 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const bool lane_loads = col_in[0] && col_in[COLS - 1];  // COLS == 2: N even, xl even
 
     const double dx2 = p.dx2, inv = p.inv;
-    const bool want_res = p.D != nullptr || p.part != nullptr;
+    const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
+
+    // ---- fused prolongation input: per-lane column tables, coarse row cache ----------
+    int pc_base = 0;              // coarse column of this lane's first fine column
+    bool pc_second_shift = false; // second fine column belongs to the next coarse cell
+    double pc_hi[2] = {0.0, 0.0}, pc_lo[2] = {0.0, 0.0};
+    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}}, c_nx = {{0.0, 0.0, 0.0}};
+    int c_row = -0x40000000;      // coarse row held in c_lo (uniform)
+    if constexpr (IN == IN_PROLONG) {
+        if (lane_loads) {
+            pc_base = p.p_ocol[xl];
+            pc_second_shift = p.p_ocol[xl + 1] != pc_base;
+            pc_hi[0] = p.p_chi[xl];
+            pc_lo[0] = p.p_clo[xl];
+            pc_hi[1] = p.p_chi[xl + 1];
+            pc_lo[1] = p.p_clo[xl + 1];
+        }
+    }
+
+    // ---- fused restriction output: which coarse column this lane produces -------------
+    int rc_col = -1;          // coarse column (interior) or -1
+    bool rc_shift = false;    // its lower-left fine sample is this lane's SECOND column
+    double rw_a = 0.0, rw_b = 0.0;
+    Row<COLS> d_prev;         // signed residual of the previous row
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) d_prev.v[j] = 0.0;
+    if constexpr (RESTRICT) {
+        if (lane_owns) {
+            const int ca = p.r_inv[xl], cb = p.r_inv[xl + 1];
+            rc_col = ca >= 0 ? ca : cb;
+            rc_shift = ca < 0 && cb >= 0;
+            if (rc_col >= 0) {
+                rw_a = p.r_w[rc_col];
+                rw_b = 1.0 - rw_a;  // src/MG_solver_CPU.cpp:665
+            }
+        }
+    }
 
     // register state: two-row history per level, F delay line, prefetch FIFO
     Row<COLS> older[S + 1], newer[S + 1], fq[S + 2];
@@ -166,9 +248,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 #pragma unroll
         for (int j = 0; j < COLS; ++j) fq[l].v[j] = 0.0;
 
-    const int y_first = y0 - (S + 1);           // first input row
-    const int T = (y1 - y0) + 2 * (S + 1);      // input rows consumed
-    const int y_end = y_first + T;              // one past the last input row
+    const int y_first = y0 - (S + 1);                             // first input row
+    const int T = (y1 - y0) + 2 * (S + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
+    const int y_end = y_first + T;                                // one past the last input row
     const size_t col_off = (size_t)(xl < 0 ? 0 : xl);
 
     Row<COLS> pu[PF], pf[PF];
@@ -177,7 +259,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         const int y = y_first + k;
         const bool ok = lane_loads && y >= 0 && y < N && y < y_end;
         const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
-        if constexpr (!ZERO_IN) pu[k] = load_row<COLS>(p.in + off, ok);
+        if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
         pf[k] = load_row<COLS>(p.F + off, ok);
     }
 
@@ -188,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         for (int k = 0; k < PF; ++k) {
             const int yin = y_first + t0 + k;
             Row<COLS> nw, cf = pf[k];
-            if constexpr (ZERO_IN) {
+            if constexpr (IN == IN_ZERO) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) nw.v[j] = 0.0;
             } else {
@@ -198,9 +280,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 const int y = yin + PF;
                 const bool ok = lane_loads && y >= 0 && y < N && y < y_end;
                 const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
-                if constexpr (!ZERO_IN) pu[k] = load_row<COLS>(p.in + off, ok);
+                if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
                 pf[k] = load_row<COLS>(p.F + off, ok);
             }
+
+            if constexpr (IN == IN_PROLONG) {
+                // level 0 = U + P(coarse): doProlongation :700 as a gather, then
+                // doGridAddition :569 (U1 = U1 + U2)
+                if (yin >= 0 && yin < N && yin < y_end) {
+                    const int i = p.p_orow[yin];  // wave-uniform
+                    if (i != c_row) {
+                        if (i == c_row + 1) {  // the owner row advanced by one: rotate
+                            c_lo = c_hi;
+                            c_hi = c_nx;
+                        } else {
+                            c_lo = load_coarse(p.coarse, p.Nc, i, pc_base, lane_loads);
+                            c_hi = load_coarse(p.coarse, p.Nc, i + 1, pc_base, lane_loads);
+                        }
+                        c_nx = load_coarse(p.coarse, p.Nc, i + 2, pc_base, lane_loads);  // one coarse row ahead
+                        c_row = i;
+                    }
+                    const double yh = p.p_rhi[yin], yl = p.p_rlo[yin];
+                    const double c_dx = p.c_dx;
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) {
+                        const bool sh = j == 1 && pc_second_shift;
+                        const double c1 = sh ? c_lo.v[1] : c_lo.v[0], c2 = sh ? c_lo.v[2] : c_lo.v[1];
+                        const double c3 = sh ? c_hi.v[1] : c_hi.v[0], c4 = sh ? c_hi.v[2] : c_hi.v[1];
+                        const double xh = pc_hi[j], xlo = pc_lo[j];
+                        const double pv = ((c1 * xh + c2 * xlo) * yh + (c3 * xh + c4 * xlo) * yl) / c_dx / c_dx;
+                        nw.v[j] = lane_loads ? nw.v[j] + pv : 0.0;
+                    }
+                }
+            }
+
 #pragma unroll
             for (int l = S + 1; l >= 1; --l) fq[l] = fq[l - 1];
             fq[0] = cf;
@@ -250,11 +363,33 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const double r = inv * (nw.v[j] + so.v[j] + e + w - 4 * c.v[j]) - fq[S + 1].v[j];
                     const bool interior = !(row_edge || col_edge[j]);
                     const double dv = interior ? r : 0.0;
-                    d.v[j] = p.d_sign < 0 ? -dv : dv;
+                    d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
                     // (row+col) even interior points only, :610/:617
                     if (mine && interior && (((y & 1) == 0) == col_even[j])) acc += fabs(r);
                 }
                 if (mine && p.D) store_row<COLS>(p.D + (size_t)y * N + xl, d);
+
+                if constexpr (RESTRICT) {
+                    // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
+                    // rc has its lower-left sample in fine row y-1
+                    const int yl = y - 1;
+                    if (yl >= y0 && yl < y1) {                  // wave-uniform
+                        const int rc_row = p.r_inv[yl];         // wave-uniform, -1: no coarse row here
+                        if (rc_row >= 0) {
+                            const double wc = p.r_w[rc_row], wd = 1.0 - wc;  // c, d of :664-666
+                            const double p_up = from_lane_above(d_prev.v[0]);
+                            const double q_up = from_lane_above(d.v[0]);
+                            const double u0 = rc_shift ? d_prev.v[1] : d_prev.v[0];
+                            const double u1 = rc_shift ? p_up : d_prev.v[1];
+                            const double u2 = rc_shift ? d.v[1] : d.v[0];
+                            const double u3 = rc_shift ? q_up : d.v[1];
+                            // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
+                            const double vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
+                            if (rc_col >= 0) p.Fc[(size_t)rc_row * p.M + rc_col] = vc;
+                        }
+                    }
+                    d_prev = d;
+                }
             }
             older[S] = newer[S];
             newer[S] = nw;
@@ -267,23 +402,35 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     }
 }
 
+// rim of the next level's F: memset(U_c, 0) of doRestriction (:651) for the points the
+// fused restriction never writes
+__global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    Uc[i] = 0.0;
+    Uc[(size_t)(M - 1) * M + i] = 0.0;
+    Uc[(size_t)i * M] = 0.0;
+    Uc[(size_t)i * M + M - 1] = 0.0;
+}
+
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
 // this instantiation x CUs) where the grid is large enough, never fewer than 32 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
-template <int S, int COLS, bool ZERO_IN>
+template <int S, int COLS, int IN, bool RESTRICT>
 void launch_k(hipStream_t s, StreamParams p, double *err_out)
 {
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, ZERO_IN>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
         blocks_per_cu = n > 8 ? 8 : n;
     }
     const int N = p.N;
-    constexpr int OW = 64 * COLS - 2 * Halo<S>::value;
+    constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT>::value;
     const int strips = (N + OW - 1) / OW;
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     const int resident = ctx().n_cu * blocks_per_cu;
@@ -304,20 +451,27 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         // waves whose strip lies outside the grid exit without writing their slot
         (void)hipMemsetAsync(p.part, 0, n_part * sizeof(double), s);
     }
+    if (RESTRICT) hipLaunchKernelGGL(k_zero_rim, dim3((p.M + 255) / 256), dim3(256), 0, s, p.M, p.Fc);
     const int grid = ((p.n_blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, ZERO_IN>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
     if (err_out) finish_smoothing_error(s, p.part, n_part, N, err_out);
 }
 
-template <int COLS>
-void launch(hipStream_t s, const StreamParams &p, int steps, double *err_out)
+template <int S>
+void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
-    const bool z = p.in == nullptr;
-    switch (steps) {
-        case 1: z ? launch_k<1, COLS, true>(s, p, err_out) : launch_k<1, COLS, false>(s, p, err_out); break;
-        case 2: z ? launch_k<2, COLS, true>(s, p, err_out) : launch_k<2, COLS, false>(s, p, err_out); break;
-        case 3: z ? launch_k<3, COLS, true>(s, p, err_out) : launch_k<3, COLS, false>(s, p, err_out); break;
-        default: z ? launch_k<4, COLS, true>(s, p, err_out) : launch_k<4, COLS, false>(s, p, err_out); break;
+    const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
+    if (p.N % 2 != 0) {  // 8 B lanes: odd row pitch; the fused transfer stages are not built for it
+        if (zero) launch_k<S, 1, IN_ZERO, false>(s, p, err_out);
+        else launch_k<S, 1, IN_LOAD, false>(s, p, err_out);
+    } else if (restrict_out) {
+        if (zero) launch_k<S, 2, IN_ZERO, true>(s, p, err_out);
+        else launch_k<S, 2, IN_LOAD, true>(s, p, err_out);
+    } else if (prolong_in) {
+        launch_k<S, 2, IN_PROLONG, false>(s, p, err_out);
+    } else {
+        if (zero) launch_k<S, 2, IN_ZERO, false>(s, p, err_out);
+        else launch_k<S, 2, IN_LOAD, false>(s, p, err_out);
     }
 }
 
@@ -325,15 +479,21 @@ void launch(hipStream_t s, const StreamParams &p, int steps, double *err_out)
 
 int stream_max_steps() { return MAX_S; }
 bool stream_supported(int N) { return N >= 3; }
+bool stream_fusable(int N) { return N >= 4 && N % 2 == 0; }
 
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out,
-                   int steps, double *err_out, double *D_out, int d_sign, const double *, int, const ProlongTable *)
+                   int steps, double *err_out, double *D_out, int d_sign, const double *coarse, int Nc,
+                   const ProlongTable *pt, double *Fc, int M, const RestrictTable *rt)
 {
     if (steps < 1 || steps > MAX_S) {
         fail(MG_ERR_ARG, "jacobi_stream: %d sweeps per launch (1..%d)", steps, MAX_S);
         return;
     }
-    StreamParams p;
+    if ((coarse || Fc) && !stream_fusable(N)) {
+        fail(MG_ERR_ARG, "jacobi_stream: fused transfer stages need an even grid size (N=%d)", N);
+        return;
+    }
+    StreamParams p = {};
     p.N = N;
     p.dx2 = dx2;
     p.inv = inv;
@@ -342,10 +502,29 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
     p.out = out;
     p.D = D_out;
     p.d_sign = d_sign;
-    p.part = nullptr;
-    p.rows_per_chunk = p.groups = p.n_blocks = 0;
-    if (N % 2 == 0) launch<2>(s, p, steps, err_out);  // 16 B lanes need an even row pitch
-    else launch<1>(s, p, steps, err_out);
+    if (coarse) {
+        p.coarse = coarse;
+        p.Nc = Nc;
+        p.p_orow = pt->owner_row;
+        p.p_ocol = pt->owner_col;
+        p.p_rhi = pt->row_hi;
+        p.p_rlo = pt->row_lo;
+        p.p_chi = pt->col_hi;
+        p.p_clo = pt->col_lo;
+        p.c_dx = pt->c_dx;
+    }
+    if (Fc) {
+        p.Fc = Fc;
+        p.M = M;
+        p.r_inv = rt->inv;
+        p.r_w = rt->w;
+    }
+    switch (steps) {
+        case 1: launch_steps<1>(s, p, err_out); break;
+        case 2: launch_steps<2>(s, p, err_out); break;
+        case 3: launch_steps<3>(s, p, err_out); break;
+        default: launch_steps<4>(s, p, err_out); break;
+    }
 }
 
 }  // namespace k

@@ -109,6 +109,16 @@ const RestrictTable &restrict_table(int N, int M)
     } else {
         t.lo = upload(lo);
         t.w = upload(w);
+        // inverse map for the fused restriction: fine index -> the interior coarse index whose
+        // lower-left sample it is.  Usable when consecutive samples are >= 2 apart.
+        std::vector<int> inv((size_t)N, -1);
+        bool ok = M >= 3;
+        for (int i = 1; i < M - 1; ++i) {
+            if (i > 1 && lo[i] - lo[i - 1] < 2) ok = false;
+            inv[(size_t)lo[i]] = i;
+        }
+        t.inv = upload(inv);
+        t.fusable = ok;
     }
     return c.rtab.emplace(key, t).first->second;
 }
@@ -124,9 +134,12 @@ const ProlongTable &prolong_table(int N, int M)
     build_prolongation_table(N, M, 0, orow.data(), rh.data(), rl.data());
     build_prolongation_table(N, M, 1, ocol.data(), ch.data(), cl.data());
     ProlongTable t;
-    bool ok = true;
+    bool ok = true, fusable = true;
     for (int k = 0; k < M; ++k) {
         if (orow[k] > N - 2 || ocol[k] > N - 2) ok = false;
+        if (orow[k] < 0 || ocol[k] < 0) fusable = false;
+        if (k > 0 && (ocol[k] - ocol[k - 1] < 0 || ocol[k] - ocol[k - 1] > 1)) fusable = false;
+        if (k > 0 && orow[k] < orow[k - 1]) fusable = false;
     }
     if (!ok) {
         fail(MG_ERR_ARG, "doProlongation: table for %d -> %d is out of bounds", N, M);
@@ -138,6 +151,7 @@ const ProlongTable &prolong_table(int N, int M)
         t.col_hi = upload(ch);
         t.col_lo = upload(cl);
         t.c_dx = 1.0 / (double)(N - 1);
+        t.fusable = fusable;
     }
     return c.ptab.emplace(key, t).first->second;
 }

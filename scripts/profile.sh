@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel trace + HBM counters of bench.py.
+#   scripts/profile.sh <tag> [bench args...]
+# Writes raw output under gpurun_out/prof_<tag>/ and a summary gpurun_out/prof_<tag>/summary.md
+# (copy the summary into profiles/ to have it judged).
+set -e
+TAG=${1:-r01}; shift || true
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 2 --no-cpu $@"
+# 1. kernel trace + stats (no counters)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
+# 2./3. HBM counters, one pass each (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.log
+python3 $ROOT/scripts/summarize_profile.py $OUT $TAG > $OUT/summary.md
+tail -40 $OUT/summary.md

@@ -60,6 +60,70 @@ def test_smoothing_fused_forms(mg, oracle, smoother, N, L):
         assert_bits(D.to_host(), oracle.getResidual(N, L, want, F), "fused +residual")
 
 
+@pytest.mark.parametrize("N,M", [(8, 4), (16, 8), (64, 32), (100, 50), (256, 128), (1024, 512), (2048, 1024),
+                                  (33, 16), (16, 15), (100, 37), (250, 124)])
+@pytest.mark.parametrize("step", [1, 2, 3, 4, 6])
+def test_fused_smooth_restrict_vs_oracle(mg, oracle, smoother, N, M, step):
+    """One "-1" node (src/MG_solver_CPU.cpp:252-287): [zero U,] smooth, residual, sign flip,
+    restrict -- fused into one pass where the streaming kernel can, operator by operator
+    otherwise (odd N, non-nested sizes, simple smoother); always the oracle's bits."""
+    U0, F = rand_pair(N, 11 * N + M)
+    Fd = mg.DeviceGrid.from_host(F)
+    for zero in (True, False):
+        start = np.zeros((N, N)) if zero else U0
+        want_U, want_err = oracle.doSmoothing(N, 1.0, start, F, step)
+        want_Fc = oracle.doRestriction(N, -oracle.getResidual(N, 1.0, want_U, F), M)
+        out = mg.DeviceGrid.from_host(np.full((N, N), np.nan))
+        Fc = mg.DeviceGrid.from_host(np.full((M, M), np.nan))
+        Uin = None if zero else mg.DeviceGrid.from_host(U0)
+        err = mg.smooth_restrict(N, 1.0, Uin, out, Fd, step, M, Fc, want_error=True)
+        assert_bits(out.to_host(), want_U, f"smooth_restrict U N={N} step={step} zero={zero}")
+        assert_bits(Fc.to_host(), want_Fc, f"smooth_restrict F_coarse {N}->{M} step={step} zero={zero}")
+        assert err == pytest.approx(want_err, rel=REL)
+
+
+@pytest.mark.parametrize("Nc,N", [(4, 8), (8, 16), (32, 64), (50, 100), (128, 256), (512, 1024), (1024, 2048),
+                                   (16, 33), (15, 16), (37, 100), (124, 250)])
+@pytest.mark.parametrize("step", [1, 2, 3, 4, 6])
+def test_fused_prolong_smooth_vs_oracle(mg, oracle, smoother, Nc, N, step):
+    """One "1" node (src/MG_solver_CPU.cpp:353-416): prolong, add, smooth."""
+    rng = np.random.default_rng(13 * N + Nc)
+    Uc, Uf, F = rng.random((Nc, Nc)) - 0.5, rng.random((N, N)), rng.random((N, N)) - 0.5
+    want0 = oracle.doGridAddition(N, Uf, oracle.doProlongation(Nc, Uc, N, fill=0.0))
+    want, want_err = oracle.doSmoothing(N, 1.0, want0, F, step)
+    out = mg.DeviceGrid.from_host(np.full((N, N), np.nan))
+    err = mg.prolong_smooth(Nc, mg.DeviceGrid.from_host(Uc), N, 1.0, mg.DeviceGrid.from_host(Uf), out,
+                            mg.DeviceGrid.from_host(F), step, want_error=True)
+    assert_bits(out.to_host(), want, f"prolong_smooth {Nc}->{N} step={step}")
+    assert err == pytest.approx(want_err, rel=REL)
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_fullsize_fused_nodes_match_unfused(mg, N):
+    """At benchmark size the fused node kernels must reproduce the operator-by-operator
+    sequence (itself pinned to the reference by the checksum tests) bit for bit."""
+    M = N // 2
+    F = mg.DeviceGrid.uniform(N, 7)
+    # down: zero start
+    U1, D, Fc1 = mg.DeviceGrid(N), mg.DeviceGrid(N), mg.DeviceGrid(M)
+    mg.smooth_pp(N, 1.0, None, U1, F, 3, D_out=D, d_sign=-1)
+    mg.doRestriction(N, D, M, Fc1)
+    U2, Fc2 = mg.DeviceGrid(N), mg.DeviceGrid(M)
+    mg.smooth_restrict(N, 1.0, None, U2, F, 3, M, Fc2)
+    assert U1.checksum() == U2.checksum()
+    assert Fc1.checksum() == Fc2.checksum()
+    # up
+    Uc = mg.DeviceGrid.uniform(M, 8)
+    mg.prolongAdd(M, Uc, N, U1, D)          # D = U1 + P(Uc)
+    mg.smooth_pp(N, 1.0, D, U2, F, 3)       # U2 = smooth^3(D)
+    O = mg.DeviceGrid(N)
+    mg.prolong_smooth(M, Uc, N, 1.0, U1, O, F, 3)
+    assert O.checksum() == U2.checksum()
+    for g in (F, U1, D, Fc1, U2, Fc2, Uc, O):
+        g.free()
+    mg.lib().mg_pool_trim()
+
+
 @pytest.mark.parametrize("N", SIZES)
 def test_residual_add_negate_vs_oracle(mg, oracle, N):
     U0, F = rand_pair(N, 3 * N)
