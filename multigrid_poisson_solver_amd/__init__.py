@@ -360,8 +360,11 @@ class CyclePlan:
     def __init__(self, path, fused=True, graph=False, report=True, error=True):
         flags = ((MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) |
                  (MG_CYCLE_REPORT if report else 0) | (MG_CYCLE_ERROR if error else 0))
-        with open(path) as f:
-            head = f.read().split()[:3]
+        try:
+            with open(path) as f:
+                head = f.read().split()[:3]
+        except OSError as e:
+            raise MGError(f"Cannot open file {path}") from e  # src/MG_solver_CPU.cpp:65-68
         self.L, self.min_x, self.min_y = (float(t) for t in head)
         self._plan = lib().mg_cycle_load(os.fsencode(path), flags)
         _check()

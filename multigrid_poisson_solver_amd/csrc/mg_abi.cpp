@@ -308,6 +308,7 @@ void mg_finalize(void)
         (void)hipFree(kv.second.lo);
         (void)hipFree(kv.second.w);
         (void)hipFree(kv.second.inv);
+        (void)hipFree(kv.second.inv_w);
     }
     for (auto &kv : c.ptab) {
         (void)hipFree(kv.second.owner_row);

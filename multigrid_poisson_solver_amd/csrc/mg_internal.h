@@ -40,6 +40,7 @@ struct RestrictTable {
     int *lo = nullptr;     // [M] lower-left fine index
     double *w = nullptr;   // [M] weight a (resp. c)
     int *inv = nullptr;    // [N] fine index -> interior coarse index with lo[] == it, else -1
+    double *inv_w = nullptr; // [N] w[inv[x]] (0 where inv[x] < 0)
     bool fusable = false;  // lo[] strictly increasing by >= 2: one coarse sample per column pair
 };
 struct ProlongTable {

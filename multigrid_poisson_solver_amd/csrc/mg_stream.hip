@@ -70,12 +70,13 @@ struct StreamParams {
     int Nc;
     const int *p_orow, *p_ocol;
     const double *p_rhi, *p_rlo, *p_chi, *p_clo;
-    double c_dx;
+    double c_dx, c_dx_rcp;   // coarse spacing and RN(1/c_dx)
     // RESTRICT: next level's F and the host-built tables of doRestriction
     double *Fc;
     int M;
     const int *r_inv;   // [N] fine index -> coarse index whose lower-left sample it is, or -1
-    const double *r_w;  // [M]
+    const double *r_w;  // [M] weights by coarse index
+    const double *r_wf; // [N] r_w[r_inv[x]] by fine index (0 where r_inv < 0)
 };
 
 // value of the neighbouring lane (lane-1 / lane+1); lanes at the wave edge read 0
@@ -95,6 +96,29 @@ __device__ __forceinline__ double from_lane_above(double v)
     r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xf, 0xf, false);
     return r.d;
 }
+
+// x / c for a constant c whose correctly rounded reciprocal rc = RN(1/c) was formed on the
+// host.  q0 = RN(x*rc) is within 2 ulp of x/c; one residual correction makes it faithful and,
+// by Markstein's theorem (r = x - c*q exact through the FMA, rc correctly rounded), a second
+// one yields RN(x/c): the same bits as the IEEE division the reference performs in
+// doProlongation (src/MG_solver_CPU.cpp:700 ".../c_dx/c_dx"), in 5 instructions instead of
+// the ~14 of the hardware division sequence.  Inputs here are ordinary finite numbers.
+__device__ __forceinline__ double div_by_const(double x, double c, double rc)
+{
+    double q = x * rc;
+    double r = __builtin_fma(-q, c, x);
+    q = __builtin_fma(r, rc, q);
+    r = __builtin_fma(-q, c, x);
+    return __builtin_fma(r, rc, q);
+}
+
+// Read-only host-built tables are read through the constant address space: the compiler may
+// then use scalar loads (s_load, SGPR result, lgkmcnt) for wave-uniform indices instead of
+// vector loads that would queue behind the streaming loads in vmcnt order.
+typedef const int __attribute__((address_space(4))) *const_int_ptr;
+typedef const double __attribute__((address_space(4))) *const_f64_ptr;
+__device__ __forceinline__ int table_i(const int *t, int i) { return ((const_int_ptr)(uintptr_t)t)[i]; }
+__device__ __forceinline__ double table_d(const double *t, int i) { return ((const_f64_ptr)(uintptr_t)t)[i]; }
 
 template <int COLS>
 struct Row {
@@ -205,8 +229,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     int pc_base = 0;              // coarse column of this lane's first fine column
     bool pc_second_shift = false; // second fine column belongs to the next coarse cell
     double pc_hi[2] = {0.0, 0.0}, pc_lo[2] = {0.0, 0.0};
-    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}}, c_nx = {{0.0, 0.0, 0.0}};
-    int c_row = -0x40000000;      // coarse row held in c_lo (uniform)
+    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}}, c_n1 = {{0.0, 0.0, 0.0}}, c_n2 = {{0.0, 0.0, 0.0}};
+    int c_row = -0x40000000;      // coarse row held in c_lo (uniform); c_hi, c_n1, c_n2 = the next three
     if constexpr (IN == IN_PROLONG) {
         if (lane_loads) {
             pc_base = p.p_ocol[xl];
@@ -253,14 +277,38 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const int y_end = y_first + T;                                // one past the last input row
     const size_t col_off = (size_t)(xl < 0 ? 0 : xl);
 
+    // wave-uniform per-row table entries travel through the same FIFO as the rows they
+    // belong to, so their (scalar) loads are issued PF iterations before use
     Row<COLS> pu[PF], pf[PF];
+    int q_own[PF];                // IN_PROLONG: owner coarse row of the input row
+    double q_yh[PF], q_yl[PF];    // IN_PROLONG: its two row weights
+    int q_rc[PF];                 // RESTRICT: coarse row sampled at fine row (input row - S - 2)
+    double q_rw[PF];              // RESTRICT: its weight c
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int y = y_first + k;
-        const bool ok = lane_loads && y >= 0 && y < N && y < y_end;
+        const bool row_ok = y >= 0 && y < N && y < y_end;
+        const bool ok = lane_loads && row_ok;
         const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
         if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
         pf[k] = load_row<COLS>(p.F + off, ok);
+        q_own[k] = -1;
+        q_yh[k] = q_yl[k] = q_rw[k] = 0.0;
+        q_rc[k] = -1;
+        if constexpr (IN == IN_PROLONG) {
+            if (row_ok) {
+                q_own[k] = table_i(p.p_orow, y);
+                q_yh[k] = table_d(p.p_rhi, y);
+                q_yl[k] = table_d(p.p_rlo, y);
+            }
+        }
+        if constexpr (RESTRICT) {
+            const int yl = y - S - 2;
+            if (yl >= y0 && yl < y1) {
+                q_rc[k] = table_i(p.r_inv, yl);
+                q_rw[k] = table_d(p.r_wf, yl);
+            }
+        }
     }
 
     double acc = 0.0;
@@ -276,39 +324,61 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             } else {
                 nw = pu[k];
             }
+            const int own_i = q_own[k];
+            const double own_yh = q_yh[k], own_yl = q_yl[k];
+            const int rc_row = q_rc[k];
+            const double rc_w = q_rw[k];
             {   // refill this FIFO slot with the row PF ahead
                 const int y = yin + PF;
-                const bool ok = lane_loads && y >= 0 && y < N && y < y_end;
+                const bool row_ok = y >= 0 && y < N && y < y_end;
+                const bool ok = lane_loads && row_ok;
                 const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
                 if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
                 pf[k] = load_row<COLS>(p.F + off, ok);
+                if constexpr (IN == IN_PROLONG) {
+                    q_own[k] = -1;
+                    if (row_ok) {
+                        q_own[k] = table_i(p.p_orow, y);
+                        q_yh[k] = table_d(p.p_rhi, y);
+                        q_yl[k] = table_d(p.p_rlo, y);
+                    }
+                }
+                if constexpr (RESTRICT) {
+                    const int yl = y - S - 2;
+                    q_rc[k] = -1;
+                    if (yl >= y0 && yl < y1) {
+                        q_rc[k] = table_i(p.r_inv, yl);
+                        q_rw[k] = table_d(p.r_wf, yl);
+                    }
+                }
             }
 
             if constexpr (IN == IN_PROLONG) {
                 // level 0 = U + P(coarse): doProlongation :700 as a gather, then
-                // doGridAddition :569 (U1 = U1 + U2)
-                if (yin >= 0 && yin < N && yin < y_end) {
-                    const int i = p.p_orow[yin];  // wave-uniform
-                    if (i != c_row) {
-                        if (i == c_row + 1) {  // the owner row advanced by one: rotate
+                // doGridAddition :569 (U1 = U1 + U2).  own_i is wave-uniform.
+                if (own_i >= 0) {
+                    if (own_i != c_row) {
+                        if (own_i == c_row + 1) {  // the owner row advanced by one: rotate
                             c_lo = c_hi;
-                            c_hi = c_nx;
-                        } else {
-                            c_lo = load_coarse(p.coarse, p.Nc, i, pc_base, lane_loads);
-                            c_hi = load_coarse(p.coarse, p.Nc, i + 1, pc_base, lane_loads);
+                            c_hi = c_n1;
+                            c_n1 = c_n2;
+                        } else {                   // first row of the chunk (or a jump)
+                            c_lo = load_coarse(p.coarse, p.Nc, own_i, pc_base, lane_loads);
+                            c_hi = load_coarse(p.coarse, p.Nc, own_i + 1, pc_base, lane_loads);
+                            c_n1 = load_coarse(p.coarse, p.Nc, own_i + 2, pc_base, lane_loads);
                         }
-                        c_nx = load_coarse(p.coarse, p.Nc, i + 2, pc_base, lane_loads);  // one coarse row ahead
-                        c_row = i;
+                        c_n2 = load_coarse(p.coarse, p.Nc, own_i + 3, pc_base, lane_loads);  // two coarse rows ahead
+                        c_row = own_i;
                     }
-                    const double yh = p.p_rhi[yin], yl = p.p_rlo[yin];
-                    const double c_dx = p.c_dx;
+                    const double c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
 #pragma unroll
                     for (int j = 0; j < COLS; ++j) {
                         const bool sh = j == 1 && pc_second_shift;
                         const double c1 = sh ? c_lo.v[1] : c_lo.v[0], c2 = sh ? c_lo.v[2] : c_lo.v[1];
                         const double c3 = sh ? c_hi.v[1] : c_hi.v[0], c4 = sh ? c_hi.v[2] : c_hi.v[1];
                         const double xh = pc_hi[j], xlo = pc_lo[j];
-                        const double pv = ((c1 * xh + c2 * xlo) * yh + (c3 * xh + c4 * xlo) * yl) / c_dx / c_dx;
+                        const double num = (c1 * xh + c2 * xlo) * own_yh + (c3 * xh + c4 * xlo) * own_yl;
+                        const double pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
                         nw.v[j] = lane_loads ? nw.v[j] + pv : 0.0;
                     }
                 }
@@ -372,11 +442,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
                     // rc has its lower-left sample in fine row y-1
-                    const int yl = y - 1;
-                    if (yl >= y0 && yl < y1) {                  // wave-uniform
-                        const int rc_row = p.r_inv[yl];         // wave-uniform, -1: no coarse row here
+                    // (rc_row / rc_w came through the FIFO: wave-uniform, -1 = no coarse row has its
+                    // lower-left sample in fine row y-1 of this chunk)
+                    {
                         if (rc_row >= 0) {
-                            const double wc = p.r_w[rc_row], wd = 1.0 - wc;  // c, d of :664-666
+                            const double wc = rc_w, wd = 1.0 - wc;  // c, d of :664-666
                             const double p_up = from_lane_above(d_prev.v[0]);
                             const double q_up = from_lane_above(d.v[0]);
                             const double u0 = rc_shift ? d_prev.v[1] : d_prev.v[0];
@@ -512,12 +582,14 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
         p.p_chi = pt->col_hi;
         p.p_clo = pt->col_lo;
         p.c_dx = pt->c_dx;
+        p.c_dx_rcp = 1.0 / pt->c_dx;  // IEEE division on the host: correctly rounded
     }
     if (Fc) {
         p.Fc = Fc;
         p.M = M;
         p.r_inv = rt->inv;
         p.r_w = rt->w;
+        p.r_wf = rt->inv_w;
     }
     switch (steps) {
         case 1: launch_steps<1>(s, p, err_out); break;

@@ -112,12 +112,15 @@ const RestrictTable &restrict_table(int N, int M)
         // inverse map for the fused restriction: fine index -> the interior coarse index whose
         // lower-left sample it is.  Usable when consecutive samples are >= 2 apart.
         std::vector<int> inv((size_t)N, -1);
+        std::vector<double> inv_w((size_t)N, 0.0);
         bool ok = M >= 3;
         for (int i = 1; i < M - 1; ++i) {
             if (i > 1 && lo[i] - lo[i - 1] < 2) ok = false;
             inv[(size_t)lo[i]] = i;
+            inv_w[(size_t)lo[i]] = w[i];
         }
         t.inv = upload(inv);
+        t.inv_w = upload(inv_w);
         t.fusable = ok;
     }
     return c.rtab.emplace(key, t).first->second;
