@@ -146,6 +146,54 @@ ProfScope::~ProfScope()
     (void)hipEventRecord(c.prof[slot].e1, c.stream);
 }
 
+double *norm_partials(size_t n)
+{
+    Context &c = ctx();
+    if (!c.defer_norms) return partials(n);
+    if (c.norm_arena_used + n > c.norm_arena_cap) {
+        // grow; what is pending keeps pointing into the old arena, which stays alive
+        size_t cap = c.norm_arena_cap ? c.norm_arena_cap * 2 : (size_t)1 << 16;
+        while (cap < n) cap *= 2;
+        if (c.norm_arena) c.retired.push_back(c.norm_arena);
+        c.norm_arena = nullptr;
+        if (!MG_HIP(hipMalloc((void **)&c.norm_arena, cap * sizeof(double)))) return nullptr;
+        c.norm_arena_cap = cap;
+        c.norm_arena_used = 0;
+    }
+    double *p = c.norm_arena + c.norm_arena_used;
+    c.norm_arena_used += n;
+    return p;
+}
+
+void norm_finish(hipStream_t s, const double *part, size_t n, int N, double *out)
+{
+    Context &c = ctx();
+    if (!c.defer_norms) {
+        k::finish_smoothing_error(s, part, n, N, out);
+        return;
+    }
+    c.pending_norms.push_back(Context::PendingNorm{part, (int)n, N, out});
+    if ((int)c.pending_norms.size() >= k::MAX_NORMS_PER_FLUSH) flush_norms();
+}
+
+void flush_norms()
+{
+    Context &c = ctx();
+    if (c.pending_norms.empty()) return;
+    k::NormBatch b;
+    int count = 0;
+    for (const auto &pn : c.pending_norms) {
+        b.part[count] = pn.part;
+        b.out[count] = pn.out;
+        b.n[count] = pn.n;
+        b.N[count] = pn.N;
+        ++count;
+    }
+    k::finish_smoothing_errors(c.stream, b, count);
+    c.pending_norms.clear();
+    c.norm_arena_used = 0;  // stream order: later partials are written after this reduction ran
+}
+
 namespace {
 
 struct Scalars {  // slots inside ctx().scalars
@@ -322,6 +370,10 @@ void mg_finalize(void)
     c.ptab.clear();
     c.pool.trim();
     (void)hipFree(c.partials);
+    (void)hipFree(c.norm_arena);
+    c.norm_arena = nullptr;
+    c.norm_arena_cap = c.norm_arena_used = 0;
+    c.pending_norms.clear();
     for (void *r : c.retired) (void)hipFree(r);
     c.retired.clear();
     c.partials = nullptr;
@@ -580,6 +632,8 @@ void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *err
     Context &c = ctx();
     const size_t n = (size_t)N * N;
     double *slot = c.scalars + Scalars::SMOOTH_ERR;
+    const bool deferred = c.defer_norms;  // this entry point hands the value back: finish now
+    c.defer_norms = false;
     if (step > 0) {
         // in-place semantics of the reference on top of the out-of-place kernels:
         // sweep into pool scratch, then hand the result back into U
@@ -591,6 +645,7 @@ void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *err
     } else if (error) {
         k::smoothing_error(c.stream, N, 1.0 / spacing_sq(N, L), U, F, slot);
     }
+    c.defer_norms = deferred;
     if (error) mg_download(error, slot, 1);
 }
 

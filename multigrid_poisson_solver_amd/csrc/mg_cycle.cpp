@@ -258,6 +258,7 @@ void run_nodes(Exec &x)
     mg_cycle_plan *p = x.p;
     LevelList &cycle = *p->levels;
     const bool fused = (p->flags & MG_CYCLE_FUSED) != 0;
+    x.c.defer_norms = true;
 
     for (;;) {
         int node;
@@ -386,6 +387,8 @@ void run_nodes(Exec &x)
         }
         // any other token: ignored, as the reference does
     }
+    flush_norms();  // the window's smoothing errors: one reduction launch
+    x.c.defer_norms = false;
 }
 
 // reset the level stack to the state right after getSource (:149-153)

@@ -81,6 +81,13 @@ struct Context {
     double *partials = nullptr;
     size_t partials_cap = 0;
     std::vector<void *> retired;          // outgrown scratch, kept alive for captured graphs
+    // deferred norm reductions: while a cycle plan runs, the smoothing kernels only leave
+    // per-wave partial sums in an arena; ONE kernel per flush finishes all of them
+    struct PendingNorm { const double *part; int n; int N; double *out; };
+    bool defer_norms = false;
+    std::vector<PendingNorm> pending_norms;
+    double *norm_arena = nullptr;
+    size_t norm_arena_cap = 0, norm_arena_used = 0;
     double *scalars = nullptr;            // [64] device scalars (errors, norms)
     int *gs_state = nullptr;              // [4]: done flag, iteration count, ...
     double *host_scalars = nullptr;       // pinned [64]
@@ -109,6 +116,11 @@ Context &ctx();
 bool require_ready(const char *who);
 double *partials(size_t n);   // device scratch for at least n doubles
 Pool &scratch_pool();         // where operator-internal scratch comes from
+// partial-sum storage + registration of a doSmoothing error reduction (deferred while a plan
+// runs, finished immediately otherwise).  flush_norms() finishes everything pending.
+double *norm_partials(size_t n);
+void norm_finish(hipStream_t s, const double *part, size_t n, int N, double *out);
+void flush_norms();
 
 const RestrictTable &restrict_table(int N, int M);
 const ProlongTable &prolong_table(int N, int M);
@@ -132,6 +144,14 @@ void residual(hipStream_t s, int N, double inv, const double *U, const double *F
 void smoothing_error(hipStream_t s, int N, double inv, const double *U, const double *F, double *out);
 // second stage of doSmoothing's error: *out = (sum+sum)/N/N over n per-block partials
 void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out);
+constexpr int MAX_NORMS_PER_FLUSH = 48;
+struct NormBatch {
+    const double *part[MAX_NORMS_PER_FLUSH];
+    double *out[MAX_NORMS_PER_FLUSH];
+    int n[MAX_NORMS_PER_FLUSH];
+    int N[MAX_NORMS_PER_FLUSH];
+};
+void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count);
 // temporally blocked streaming smoother (mg_stream.hip): steps <= stream_max_steps()
 int  stream_max_steps();
 bool stream_supported(int N);

@@ -142,6 +142,22 @@ __global__ __launch_bounds__(1024) void k_finish(const double *__restrict__ part
     }
 }
 
+// many doSmoothing error reductions in one launch: block b finishes descriptor b
+__global__ __launch_bounds__(256) void k_finish_batch(const NormBatch b)
+{
+    const int d = blockIdx.x;
+    const double *__restrict__ part = b.part[d];
+    const int n = b.n[d], N = b.N[d];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) {
+        double e = s + s;  // *error = sum1+sum2; *error = *error/N/N  (:621-622)
+        e = e / N / N;
+        *b.out[d] = e;
+    }
+}
+
 // ---------------------------------------------------------------- restriction
 // src/MG_solver_CPU.cpp:656-678 with the 1-D tables built on the host from the
 // reference's floor/fmod expressions (:661-666); rim of the coarse grid is 0 (:651)
@@ -341,6 +357,72 @@ __global__ __launch_bounds__(1024) void k_gs_workgroup(int N, double h2, double 
     }
 }
 
+// grids of at most 64 points (N <= 8, the coarsest level of every shipped cycle file): ONE
+// wave, one point per lane, U in a register; neighbours through ds_bpermute, the norm
+// through a DPP row scan + 4 readlanes -- no LDS traffic, no barriers.
+template <int SHIFT>
+__device__ __forceinline__ double row_shr_zero(double v)
+{
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x110 + SHIFT, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x110 + SHIFT, 0xf, 0xf, true);
+    return r.d;
+}
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return r.d;
+}
+__device__ __forceinline__ double wave_total(double v)
+{
+    v += row_shr_zero<1>(v);
+    v += row_shr_zero<2>(v);
+    v += row_shr_zero<4>(v);
+    v += row_shr_zero<8>(v);   // lanes 15, 31, 47, 63 hold their row's total
+    return ((read_lane(v, 15) + read_lane(v, 31)) + read_lane(v, 47)) + read_lane(v, 63);
+}
+
+__global__ __launch_bounds__(64) void k_gs_wave(int N, double h2, double inv, double *__restrict__ Ug,
+                                                const double *__restrict__ Fg, double tol, int *__restrict__ state)
+{
+    const int lane = threadIdx.x;
+    const int n = N * N;
+    const int r = lane / N, c = lane - r * N;
+    const bool inside = lane < n && !rim(r, c, N);
+    const int colour = (r + c) & 1;
+    const double f = lane < n ? Fg[lane] : 0.0;
+    const double h2f = h2 * f;
+    const int l_w = lane > 0 ? lane - 1 : 0, l_e = lane < 63 ? lane + 1 : 63;
+    const int l_s = lane >= N ? lane - N : 0, l_n = lane + N < 64 ? lane + N : 63;
+    const double denom = (double)((N - 2) * (N - 2));
+    double u = 0.0;  // memset(U, 0)  :993
+    int iterations = 0;
+    for (;;) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
+            const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
+            const double nu = 0.25 * (w + e + nn + ss - h2f);  // :1020 U[l]+U[r]+U[t]+U[b] - h^2 F
+            if (inside && colour == pass) u = nu;
+        }
+        ++iterations;
+        const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
+        const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
+        const double res = inside ? fabs(inv * (nn + ss + e + w - 4 * u) - f) : 0.0;  // :560
+        const double err = wave_total(res) / denom;  // :1059
+        if (!(err > tol) || iterations >= GS_MAX_ITER) break;
+    }
+    if (lane < n) Ug[lane] = u;
+    if (lane == 0) {
+        state[0] = 1;
+        state[1] = iterations;
+    }
+}
+
 // multi-workgroup form for grids that do not fit one CU's LDS: one launch per colour
 // plus a norm; every kernel is a no-op once state[0] (done) is set, so the host may
 // enqueue iterations in batches without changing the result.
@@ -401,6 +483,11 @@ void finish(hipStream_t s, const double *part, size_t n, int mode, int N, double
 void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out)
 {
     finish(s, part, n, FIN_SMOOTH_ERR, N, out);
+}
+
+void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count)
+{
+    if (count > 0) hipLaunchKernelGGL(k_finish_batch, dim3(count), dim3(256), 0, s, b);
 }
 
 void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out)
@@ -482,6 +569,10 @@ void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const 
 {
     (void)hipMemsetAsync(state, 0, 4 * sizeof(int), s);
     const size_t n = (size_t)N * N;
+    if (n <= 64) {
+        hipLaunchKernelGGL(k_gs_wave, dim3(1), dim3(64), 0, s, N, h2, inv, U, F, tol, state);
+        return;
+    }
     if (N <= gs_single_workgroup_max_n()) {
         const bool f_in_lds = N <= 96;
         const size_t lds = n * sizeof(double) * (f_in_lds ? 2 : 1);

@@ -203,7 +203,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const int strip = group * WAVES_PER_WG + wave;
     const int N = p.N;
     const int own_x0 = strip * OW;
-    if (own_x0 >= N) return;  // no barriers in this kernel: a wave may leave at any time
+    if (own_x0 >= N) {  // no barriers in this kernel: a wave may leave at any time
+        if (p.part && lane == 0) p.part[(size_t)tile * WAVES_PER_WG + wave] = 0.0;
+        return;
+    }
     const int y0 = chunk * p.rows_per_chunk;
     int y1 = y0 + p.rows_per_chunk;
     if (y1 > N) y1 = N;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc
 }
 
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
-// this instantiation x CUs) where the grid is large enough, never fewer than 32 rows per
+// this instantiation x CUs) where the grid is large enough, never fewer than 8 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
 template <int S, int COLS, int IN, bool RESTRICT>
 void launch_k(hipStream_t s, StreamParams p, double *err_out)
@@ -505,7 +508,7 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     const int resident = ctx().n_cu * blocks_per_cu;
     int chunks = resident / groups;
-    const int max_chunks = (N + 31) / 32;
+    const int max_chunks = (N + 7) / 8;  // small grids: parallelism over halo economy
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     const int rows = (N + chunks - 1) / chunks;
@@ -516,15 +519,13 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     p.part = nullptr;
     const size_t n_part = (size_t)p.n_blocks * WAVES_PER_WG;
     if (err_out) {
-        p.part = partials(n_part);
+        p.part = norm_partials(n_part);  // every wave of every tile writes its slot
         if (!p.part) return;
-        // waves whose strip lies outside the grid exit without writing their slot
-        (void)hipMemsetAsync(p.part, 0, n_part * sizeof(double), s);
     }
     if (RESTRICT) hipLaunchKernelGGL(k_zero_rim, dim3((p.M + 255) / 256), dim3(256), 0, s, p.M, p.Fc);
     const int grid = ((p.n_blocks + 7) / 8) * 8;
     hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
-    if (err_out) finish_smoothing_error(s, p.part, n_part, N, err_out);
+    if (err_out) norm_finish(s, p.part, n_part, N, err_out);
 }
 
 template <int S>
