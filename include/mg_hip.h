@@ -192,6 +192,37 @@ int            mg_cycle_main(int argc, char **argv);
 /* CSV writer of src/MG_solver_CPU.cpp:735-754 on a device array */
 int            mg_print2File(int N, const double *U_dev, const char *file_name);
 
+/* ------------------------------------------------------------------------- */
+/* 1-D row-slab decomposition over the GPUs of one node (no reference            */
+/* counterpart: the reference is single-device, src/MG_solver_GPU.cu:58)         */
+/* ------------------------------------------------------------------------- */
+/* RCCL communicator, one process per GPU.  Rank 0 creates the id, the caller ships its
+ * mg_comm_unique_id_bytes() bytes to every rank (e.g. torch.distributed broadcast). */
+int  mg_comm_unique_id_bytes(void);
+int  mg_comm_get_unique_id(void *out);
+int  mg_comm_init(int rank, int nranks, const void *unique_id);
+void mg_comm_finalize(void);
+int  mg_comm_rank(void);
+int  mg_comm_size(void);
+
+/* host-only: row ranges per level and rank of the hierarchy N_max, N_max/2, ... >= N_min.
+ * out[(level*nranks + rank)*2 + {0,1}] = [lo, hi); collapsed_out[level] = 1 where the level
+ * lives on rank 0 only.  Returns the number of levels. */
+int  mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out);
+int  mg_slab_ghost_rows(void);
+
+typedef struct mg_slab_plan mg_slab_plan;
+/* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:
+ * all nranks slabs live in this process and exchange by device copies ("virtual ranks":
+ * how the decomposition is verified bit for bit on one GPU).  Levels with N <= collapse_N
+ * run on rank 0 only.  Supported grammar: con_N = 1, fixed con_step in 1..4, option 1. */
+mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N);
+/* one run of the reference's timed window; U_dev is NULL (use mg_slab_gather_U) */
+int  mg_slab_execute(mg_slab_plan *plan, mg_cycle_result *out);
+/* owned rows of this process's slabs of the finest U into a full N x N host array */
+int  mg_slab_gather_U(mg_slab_plan *plan, double *host_full);
+void mg_slab_destroy(mg_slab_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

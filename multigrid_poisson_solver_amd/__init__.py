@@ -68,6 +68,12 @@ ABI = {
     "mg_cycle_load": (_vp, [C.c_char_p, _i]), "mg_cycle_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_cycle_destroy": (None, [_vp]), "mg_cycle_main": (_i, [_i, C.POINTER(C.c_char_p)]),
     "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
+    "mg_comm_unique_id_bytes": (_i, []), "mg_comm_get_unique_id": (_i, [_vp]),
+    "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_rank": (_i, []),
+    "mg_comm_size": (_i, []),
+    "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
+    "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
+    "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_destroy": (None, [_vp]),
     "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
 }
 
@@ -395,6 +401,76 @@ class CyclePlan:
     def close(self):
         if self._plan and _initialised:
             _lib.mg_cycle_destroy(self._plan)
+        self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def slab_partition(N_max, N_min, nranks, collapse_N):
+    """Host-only: [(level N, collapsed, [(lo, hi) per rank])] of the row-slab decomposition."""
+    lib_ = load_library()
+    nl = lib_.mg_slab_partition(N_max, N_min, nranks, collapse_N, None, None)
+    out = np.zeros((nl, nranks, 2), dtype=np.int32)
+    coll = np.zeros(nl, dtype=np.int32)
+    lib_.mg_slab_partition(N_max, N_min, nranks, collapse_N, out.ctypes.data, coll.ctypes.data)
+    sizes, n = [], N_max
+    while n >= N_min and n > 0:
+        sizes.append(n)
+        n //= 2
+    return [(sizes[l], bool(coll[l]), [tuple(int(v) for v in out[l, r]) for r in range(nranks)]) for l in range(nl)]
+
+
+def slab_ghost_rows():
+    return load_library().mg_slab_ghost_rows()
+
+
+def comm_init(rank, nranks, unique_id_bytes):
+    buf = C.create_string_buffer(bytes(unique_id_bytes), len(unique_id_bytes))
+    if lib().mg_comm_init(rank, nranks, buf) != 0:
+        _check()
+        raise MGError("mg_comm_init failed")
+    _check()
+
+
+def comm_unique_id():
+    n = lib().mg_comm_unique_id_bytes()
+    buf = C.create_string_buffer(n)
+    if _lib.mg_comm_get_unique_id(buf) != 0:
+        _check()
+        raise MGError("mg_comm_get_unique_id failed")
+    return bytes(buf.raw)
+
+
+class SlabPlan:
+    """The cycle-file driver on a 1-D row-slab decomposition (mg_slab_*)."""
+
+    def __init__(self, path, nranks, rank=-1, collapse_N=512):
+        self._plan = lib().mg_slab_load(os.fsencode(path), nranks, rank, collapse_N)
+        _check()
+        if not self._plan:
+            raise MGError(f"cannot load cycle file {path} in row-slab mode")
+
+    def execute(self):
+        res = CycleResult()
+        status = _lib.mg_slab_execute(self._plan, C.byref(res))
+        _check()
+        return dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
+                    records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
+                             for i in range(res.n_records)])
+
+    def gather_U(self, N):
+        U = np.zeros((N, N))
+        _lib.mg_slab_gather_U(self._plan, U.ctypes.data)
+        _check()
+        return U
+
+    def close(self):
+        if self._plan and _initialised:
+            _lib.mg_slab_destroy(self._plan)
         self._plan = None
 
     def __del__(self):

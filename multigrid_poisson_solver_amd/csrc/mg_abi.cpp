@@ -496,6 +496,72 @@ void source_rows(size_t r0, size_t r1, void *arg)
 }
 }  // namespace
 
+}  // extern "C"
+
+namespace mg {
+void fill_source_rows(int N, double L, double min_x, double min_y, int row_lo, int row_hi, double *dev_dst)
+{
+    if (row_hi <= row_lo) return;
+    const size_t n = (size_t)(row_hi - row_lo) * N;
+    double *host = nullptr;
+    if (!MG_HIP(hipHostMalloc((void **)&host, n * sizeof(double), hipHostMallocDefault))) return;
+    // the job indexes rows globally; shift the destination so row row_lo lands at host[0]
+    SourceJob job{N, L / (double)(N - 1), min_x, min_y, host - (size_t)row_lo * N};
+    struct Range { SourceJob *j; int lo; } rg{&job, row_lo};
+    parallel_for((size_t)(row_hi - row_lo),
+                 [](size_t a, size_t b, void *arg) {
+                     Range *r = (Range *)arg;
+                     source_rows(a + r->lo, b + r->lo, r->j);
+                 },
+                 &rg);
+    mg_upload(dev_dst, host, n);
+    (void)hipHostFree(host);
+}
+
+// one fused launch on a row window (slab mode supports step <= stream_max_steps(): a second
+// launch would need a ghost exchange of the intermediate field)
+void slab_smooth(int N, double L, const double *U_in, double *U_out, const double *F, int step, double *raw_norm_out,
+                 const SlabFusion &sf)
+{
+    Context &c = ctx();
+    const double dx2 = spacing_sq(N, L);
+    const double inv = 1.0 / dx2;
+    if (step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N)) {
+        fail(MG_ERR_UNSUPPORTED, "row-slab mode: %d smoothing steps on N=%d (need 1..%d steps, even N)", step, N,
+             k::stream_max_steps());
+        return;
+    }
+    const ProlongTable *pt = nullptr;
+    const RestrictTable *rt = nullptr;
+    if (sf.coarse) {
+        pt = &prolong_table(sf.Nc, N);
+        if (!pt->owner_row || !pt->fusable) {
+            fail(MG_ERR_UNSUPPORTED, "row-slab mode: prolongation %d -> %d is not fusable", sf.Nc, N);
+            return;
+        }
+    }
+    if (sf.Fc) {
+        rt = &restrict_table(N, sf.M);
+        if (!rt->lo || !rt->fusable) {
+            fail(MG_ERR_UNSUPPORTED, "row-slab mode: restriction %d -> %d is not fusable", N, sf.M);
+            return;
+        }
+    }
+    const size_t n = (size_t)(sf.fine_w.own_hi - sf.fine_w.own_lo) * N;
+    double bytes = (double)n * (24.0 * step + (U_in ? 0.0 : 8.0) + (sf.Fc ? 24.0 : 0.0));
+    if (sf.Fc) bytes += 8.0 * n + 2.0 * n;
+    if (sf.coarse) bytes += 16.0 * n + 2.0 * n;
+    char name[40];
+    snprintf(name, sizeof name, "slab_stream<%d%s%s%s>", step, U_in ? "" : ",zero", sf.coarse ? ",prolong" : "",
+             sf.Fc ? ",res,restrict" : "");
+    ProfScope ps(name, N, bytes);
+    k::jacobi_stream(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, nullptr, -1, sf.coarse, sf.Nc, pt, sf.Fc,
+                     sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
+}
+}  // namespace mg
+
+extern "C" {
+
 void mg_getSource(int N, double L, double *F, double min_x, double min_y)
 {
     if (!require_ready("mg_getSource") || !grid_args_ok("mg_getSource", N)) return;

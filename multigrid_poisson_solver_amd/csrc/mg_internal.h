@@ -51,6 +51,13 @@ struct ProlongTable {
     bool fusable = false;  // every fine index owned, owners advance by <= 1 per fine index
 };
 
+// a window of grid rows held in a local array: rows [base, base+rows) of the global grid
+// (base may be negative / extend past N: those rows are never touched), of which this rank
+// owns [own_lo, own_hi).  1-D row-slab decomposition, BASELINE.json north_star.
+struct RowWindow {
+    int base = 0, rows = 0, own_lo = 0, own_hi = 0;
+};
+
 // ---------------------------------------------------------------------------
 // caching device pool (replaces malloc/free of the level arrays)
 // ---------------------------------------------------------------------------
@@ -129,6 +136,31 @@ void build_restriction_table(int N, int M, int *lo, double *w);
 void build_prolongation_table(int N, int M, int axis, int *owner, double *w_hi, double *w_lo);
 bool restriction_table_in_bounds(int N, int M, const int *lo);
 
+// getSource (src/MG_solver_CPU.cpp:468-493) for grid rows [row_lo, row_hi) evaluated on the host
+// (libm exp) into dev_dst, which points at row row_lo
+void fill_source_rows(int N, double L, double min_x, double min_y, int row_lo, int row_hi, double *dev_dst);
+// smoothing on a row window with optional fused transfer stages (mg_abi.cpp)
+struct SlabFusion {
+    const double *coarse = nullptr;
+    int Nc = 0;
+    double *Fc = nullptr;
+    int M = 0;
+    RowWindow fine_w, coarse_w, fc_w;
+};
+void slab_smooth(int N, double L, const double *U_in, double *U_out, const double *F, int step, double *raw_norm_out,
+                 const SlabFusion &sf);
+
+// RCCL transport (mg_comm.cpp)
+bool comm_ready();
+int comm_rank();
+int comm_size();
+void comm_group_begin();
+void comm_group_end();
+void comm_send(const double *buf, size_t count, int peer);
+void comm_recv(double *buf, size_t count, int peer);
+void comm_bcast(double *buf, size_t count, int root);
+void comm_allgather(const double *send, double *recv, size_t count_per_rank);
+
 // small host helper: run fn(begin,end) over [0,n) on the host threads
 void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg);
 
@@ -158,10 +190,13 @@ bool stream_supported(int N);
 bool stream_fusable(int N);   // the fused prolongation / restriction stages exist for this N
 // coarse != nullptr: level 0 is in + doProlongation(coarse) (tables pt).  Fc != nullptr: the
 // d_sign-ed residual of the result is restricted into Fc (M x M, tables rt).
+// fine_w / coarse_w / fc_w: row windows of the fine arrays, the coarse input and the coarse
+// output for the 1-D row-slab decomposition (nullptr = the whole grid is local).
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F,
                    double *out, int steps, double *err_out, double *D_out, int d_sign,
                    const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
-                   const RestrictTable *rt);
+                   const RestrictTable *rt, const RowWindow *fine_w = nullptr,
+                   const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr);
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);
@@ -170,6 +205,9 @@ void negate(hipStream_t s, size_t n, double *a);
 void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y);
 void analytic(hipStream_t s, int N, double L, double *U, double min_x, double min_y);
 void analytic_error(hipStream_t s, int N, double L, const double *U, double min_x, double min_y, double *out);
+// raw sum |analytic - U| over the owned rows of a row window (combined across slabs by the caller)
+void analytic_error_rows(hipStream_t s, int N, double L, const double *U, const RowWindow &w, double min_x,
+                         double min_y, double *out_raw);
 void fill_uniform(hipStream_t s, double *dst, size_t n, uint64_t seed);
 void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2]*/);
 // red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]

@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void k_finish_batch(const NormBatch b)
     for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
     const double s = block_sum(acc);
     if (threadIdx.x == 0) {
-        double e = s + s;  // *error = sum1+sum2; *error = *error/N/N  (:621-622)
-        e = e / N / N;
+        double e = s;
+        if (N > 0) {  // N <= 0: raw partial sum of one row slab, combined across ranks later
+            e = s + s;  // *error = sum1+sum2; *error = *error/N/N  (:621-622)
+            e = e / N / N;
+        }
         *b.out[d] = e;
     }
 }
@@ -254,6 +257,25 @@ __global__ __launch_bounds__(TB) void k_analytic_error(int N, double h, const do
         for (int k = 0; k < ROWS_PB; ++k) {
             const int r = r0 + k;
             if (r < N) acc += fabs(analytic_at(r, c, N, h, min_x, min_y) - U[(size_t)r * N + c]);
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// sum |analytic - U| over the owned rows of a row window (src/MG_solver_CPU.cpp:441-444)
+__global__ __launch_bounds__(TB) void k_analytic_error_rows(int N, double h, const double *__restrict__ U, int base,
+                                                            int own_lo, double min_x, double min_y,
+                                                            int own_hi, double *__restrict__ part)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    const int r0 = own_lo + blockIdx.y * ROWS_PB;
+    double acc = 0.0;
+    if (c < N) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PB; ++k) {
+            const int r = r0 + k;
+            if (r < own_hi) acc += fabs(analytic_at(r, c, N, h, min_x, min_y) - U[(size_t)(r - base) * N + c]);
         }
     }
     const double s = block_sum(acc);
@@ -482,7 +504,23 @@ void finish(hipStream_t s, const double *part, size_t n, int mode, int N, double
 // ------------------------------------------------------------------ launchers
 void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out)
 {
-    finish(s, part, n, FIN_SMOOTH_ERR, N, out);
+    finish(s, part, n, N > 0 ? FIN_SMOOTH_ERR : FIN_RAW, N, out);
+}
+
+void analytic_error_rows(hipStream_t s, int N, double L, const double *U, const RowWindow &w, double min_x,
+                         double min_y, double *out_raw)
+{
+    const int own = w.own_hi - w.own_lo;
+    if (own <= 0) {
+        (void)hipMemsetAsync(out_raw, 0, sizeof(double), s);
+        return;
+    }
+    const dim3 g((N + TB - 1) / TB, (own + ROWS_PB - 1) / ROWS_PB);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    hipLaunchKernelGGL(k_analytic_error_rows, g, dim3(TB), 0, s, N, L / (double)(N - 1), U, w.base, w.own_lo, min_x, min_y,
+                       w.own_hi, part);
+    finish(s, part, np, FIN_RAW, N, out_raw);
 }
 
 void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count)

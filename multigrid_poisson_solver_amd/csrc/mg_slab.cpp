@@ -1,0 +1,603 @@
+// mg_slab.cpp -- the cycle-file driver on a 1-D row-slab decomposition.
+//
+// New work with no counterpart in the reference (single device).  The
+// fine levels of the hierarchy are cut into contiguous row slabs, one per rank; a slab is one
+// contiguous block of the row-major array and a ghost row is one contiguous message.  Each
+// slab carries GHOST rows of halo on either side.  Because the smoother is temporally
+// blocked, ONE exchange of ghost rows feeds a whole fused node (S sweeps + residual +
+// restriction, or prolongation + S sweeps): per level and V-cycle there is one exchange of
+// the next level's F on the way down and one of (coarse U, fine U) on the way up.
+// Levels at or below collapse_N live on rank 0 only: their F is
+// gathered after the last distributed restriction, rank 0 runs that part of the cycle file
+// with the single-GPU operators, and the coarse correction is broadcast back.
+//
+// Ranks may all live in THIS process ("virtual ranks": exchanges are device-to-device
+// copies) -- that is how the decomposition is tested bit-for-bit on a one-GPU box -- or one
+// per process over RCCL (mg_comm.cpp), which is how bench.py --gpus N runs.
+//
+// The coarse partition is induced by the fine one: a rank owns the coarse rows whose
+// lower-left restriction sample (doRestriction's iy_f, src/MG_solver_CPU.cpp:662) lies in
+// its fine rows, so the fused restriction never writes a remote row.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "mg_internal.h"
+
+namespace mg {
+namespace {
+
+constexpr int GHOST = 6;  // >= S+2 for S <= 4 sweeps per launch (mg_stream.hip Halo<>)
+
+struct Partition {
+    std::vector<int> lo, hi;  // rows [lo[r], hi[r]) owned by global rank r
+};
+
+Partition split_rows(int N, int R)
+{
+    Partition p;
+    const int base = N / R, rem = N % R;
+    int at = 0;
+    for (int r = 0; r < R; ++r) {
+        const int n = base + (r < rem ? 1 : 0);
+        p.lo.push_back(at);
+        at += n;
+        p.hi.push_back(at);
+    }
+    return p;
+}
+
+// coarse rows owned by the rank whose fine rows hold their lower-left sample lo[rc]; the rim
+// rows 0 and M-1 (never sampled, always zero) go to the first and last rank
+Partition induced_partition(const Partition &fine, int N, int M)
+{
+    std::vector<int> lo((size_t)M);
+    std::vector<double> w((size_t)M);
+    build_restriction_table(N, M, lo.data(), w.data());
+    const int R = (int)fine.lo.size();
+    Partition c;
+    int rc = 1;
+    for (int r = 0; r < R; ++r) {
+        c.lo.push_back(rc);
+        while (rc <= M - 2 && lo[(size_t)rc] < fine.hi[(size_t)r]) ++rc;
+        c.hi.push_back(rc);
+    }
+    c.lo[0] = 0;
+    c.hi[(size_t)R - 1] = M;
+    return c;
+}
+
+int min_rows(const Partition &p)
+{
+    int m = 1 << 30;
+    for (size_t r = 0; r < p.lo.size(); ++r) m = std::min(m, p.hi[r] - p.lo[r]);
+    return m;
+}
+
+struct Local {  // one local rank's arrays of one level
+    double *U = nullptr, *F = nullptr, *D = nullptr;
+};
+
+struct Level {
+    int N = 0;
+    bool collapsed = false;   // whole grid on the root rank only
+    Partition part;           // distributed levels
+    std::vector<Local> loc;   // per local rank (collapsed: one entry, used on the root only)
+};
+
+}  // namespace
+}  // namespace mg
+
+using namespace mg;
+
+struct mg_slab_plan {
+    std::string path;
+    double L = 1.0, min_x = 0.0, min_y = 0.0;
+    int con_step = 0, con_N = 0, N_max = 0, N_min = 0;
+    std::vector<int> sizes;
+    std::vector<double> tokens;
+    int nranks = 1;
+    std::vector<int> local;   // global ranks handled by this process
+    bool real = false;        // one rank per process over RCCL
+    int collapse_N = 512;
+    Pool pool;
+    std::vector<Level> levels;
+    std::vector<Partition> parts;       // per hierarchy index (sizes[i]), distributed ones only
+    std::vector<bool> level_collapsed;  // per hierarchy index
+    std::vector<double *> stage;        // per local rank: a full coarse array at the collapse boundary
+    std::vector<mg_node_record> records;
+    std::vector<int> rec_final;         // 1: the root's slot already holds the finished value
+    double *raw_dev = nullptr;          // [max_rec][n_local] raw sums (+1 row for the analytic error)
+    double *all_dev = nullptr;          // real mode: allgather target [nranks][max_rec+1]
+    size_t max_rec = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int status = 0;
+};
+
+namespace {
+
+bool is_root_local(const mg_slab_plan *p) { return p->local[0] == 0; }
+int local_index(const mg_slab_plan *p, int global_rank)
+{
+    for (size_t i = 0; i < p->local.size(); ++i)
+        if (p->local[i] == global_rank) return (int)i;
+    return -1;
+}
+
+RowWindow window_of(const Partition &part, int r)
+{
+    RowWindow w;
+    w.own_lo = part.lo[(size_t)r];
+    w.own_hi = part.hi[(size_t)r];
+    w.base = w.own_lo - GHOST;
+    w.rows = (w.own_hi - w.own_lo) + 2 * GHOST;
+    return w;
+}
+
+double *row_ptr(double *a, const RowWindow &w, int N, int y) { return a + (size_t)(y - w.base) * N; }
+
+void alloc_level(mg_slab_plan *p, Level &lv)
+{
+    if (lv.collapsed) {
+        lv.loc.resize(1);
+        if (is_root_local(p)) {
+            const size_t bytes = (size_t)lv.N * lv.N * sizeof(double);
+            lv.loc[0].U = (double *)p->pool.get(bytes);
+            lv.loc[0].F = (double *)p->pool.get(bytes);
+            lv.loc[0].D = (double *)p->pool.get(bytes);
+        }
+        return;
+    }
+    lv.loc.resize(p->local.size());
+    for (size_t i = 0; i < p->local.size(); ++i) {
+        const RowWindow w = window_of(lv.part, p->local[i]);
+        const size_t bytes = (size_t)w.rows * lv.N * sizeof(double);
+        lv.loc[i].U = (double *)p->pool.get(bytes);
+        lv.loc[i].F = (double *)p->pool.get(bytes);
+        lv.loc[i].D = (double *)p->pool.get(bytes);
+    }
+}
+
+void free_level(mg_slab_plan *p, Level &lv)
+{
+    for (Local &l : lv.loc) {
+        if (l.U) p->pool.put(l.U);
+        if (l.F) p->pool.put(l.F);
+        if (l.D) p->pool.put(l.D);
+    }
+    lv.loc.clear();
+}
+
+// ghost rows of one array of a distributed level: every rank sends its top GHOST owned rows up
+// and its bottom GHOST owned rows down, and receives the neighbours' into its halo
+enum Which { ARR_U, ARR_F };
+void exchange_ghosts(mg_slab_plan *p, Level &lv, Which which)
+{
+    Context &c = ctx();
+    const int N = lv.N, R = p->nranks;
+    const size_t cnt = (size_t)GHOST * N;
+    auto arr = [&](size_t i) { return which == ARR_U ? lv.loc[i].U : lv.loc[i].F; };
+    if (!p->real) {
+        for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
+            const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
+            double *A = arr((size_t)r), *B = arr((size_t)r + 1);
+            // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
+            (void)hipMemcpyAsync(row_ptr(B, b, N, b.own_lo - GHOST), row_ptr(A, a, N, a.own_hi - GHOST),
+                                 cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+            (void)hipMemcpyAsync(row_ptr(A, a, N, a.own_hi), row_ptr(B, b, N, b.own_lo), cnt * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c.stream);
+        }
+        return;
+    }
+    const int r = p->local[0];
+    const RowWindow w = window_of(lv.part, r);
+    double *A = arr(0);
+    comm_group_begin();
+    if (r + 1 < R) {
+        comm_send(row_ptr(A, w, N, w.own_hi - GHOST), cnt, r + 1);
+        comm_recv(row_ptr(A, w, N, w.own_hi), cnt, r + 1);
+    }
+    if (r > 0) {
+        comm_send(row_ptr(A, w, N, w.own_lo), cnt, r - 1);
+        comm_recv(row_ptr(A, w, N, w.own_lo - GHOST), cnt, r - 1);
+    }
+    comm_group_end();
+}
+
+// rows of the full coarse array each rank produced (stage buffers) -> the root's F
+void gather_to_root(mg_slab_plan *p, const Partition &cpart, int M, double *root_F)
+{
+    Context &c = ctx();
+    if (!p->real) {
+        for (size_t i = 0; i < p->local.size(); ++i) {
+            const int r = p->local[i];
+            const size_t off = (size_t)cpart.lo[(size_t)r] * M;
+            const size_t cnt = (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M;
+            (void)hipMemcpyAsync(root_F + off, p->stage[i] + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+        }
+        return;
+    }
+    const int me = p->local[0];
+    comm_group_begin();
+    if (me == 0) {
+        const size_t cnt0 = (size_t)(cpart.hi[0] - cpart.lo[0]) * M;
+        (void)hipMemcpyAsync(root_F, p->stage[0], cnt0 * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+        for (int r = 1; r < p->nranks; ++r)
+            comm_recv(root_F + (size_t)cpart.lo[(size_t)r] * M, (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M, r);
+    } else {
+        comm_send(p->stage[0] + (size_t)cpart.lo[(size_t)me] * M, (size_t)(cpart.hi[(size_t)me] - cpart.lo[(size_t)me]) * M, 0);
+    }
+    comm_group_end();
+}
+
+// the root's full coarse U -> every local rank's stage buffer
+void broadcast_from_root(mg_slab_plan *p, int M, const double *root_U)
+{
+    Context &c = ctx();
+    const size_t cnt = (size_t)M * M;
+    if (!p->real) {
+        for (size_t i = 0; i < p->local.size(); ++i)
+            (void)hipMemcpyAsync(p->stage[i], root_U, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+        return;
+    }
+    if (p->local[0] == 0) (void)hipMemcpyAsync(p->stage[0], root_U, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+    comm_bcast(p->stage[0], cnt, 0);
+}
+
+double *raw_slot(mg_slab_plan *p, size_t rec, size_t local_i) { return p->raw_dev + rec * p->local.size() + local_i; }
+
+int add_record(mg_slab_plan *p, int node, int N, int steps, int final)
+{
+    p->records.push_back(mg_node_record{node, N, steps, 0.0});
+    p->rec_final.push_back(final);
+    return (int)p->records.size() - 1;
+}
+
+void run(mg_slab_plan *p)
+{
+    Context &c = ctx();
+    size_t tok = 0;
+    int at = 0;
+    auto next = [&](double *v) {
+        if (tok >= p->tokens.size()) return false;
+        *v = p->tokens[tok++];
+        return true;
+    };
+    const int step = p->con_step;
+    c.defer_norms = true;
+    bool came_back_up = false;  // the list has collapsed back to the finest level once
+
+    for (;;) {
+        double t;
+        if (!next(&t)) break;
+        const int node = (int)t;
+        if (node == 2) break;
+        if (c.last_error) { p->status = 10; break; }
+
+        if (node == -1) {  // smooth + residual + sign flip + restrict, src/MG_solver_CPU.cpp:252-287
+            if (at + 1 >= (int)p->sizes.size()) { p->status = 4; break; }
+            // a second descent from the finest level would keep U (restart rule :252-257): not
+            // implemented for slabs -- refuse instead of silently zeroing
+            if (p->levels.size() == 1 && came_back_up) { p->status = 13; break; }
+            const int hier = ++at;
+            const int M = p->sizes[(size_t)hier];
+            Level &cur = p->levels.back();
+            Level nxt;
+            nxt.N = M;
+            nxt.collapsed = p->level_collapsed[(size_t)hier];
+            if (!nxt.collapsed) nxt.part = p->parts[(size_t)hier];
+            alloc_level(p, nxt);
+            if ((int)p->records.size() >= (int)p->max_rec) { p->status = 11; break; }
+
+            if (cur.collapsed) {
+                const int rec = add_record(p, -1, cur.N, step, 1);
+                if (is_root_local(p))
+                    mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[0].U, cur.loc[0].F, step, raw_slot(p, (size_t)rec, 0), M,
+                                       nxt.loc[0].F);
+            } else {
+                const int rec = add_record(p, -1, cur.N, step, 0);
+                const Partition cpart = nxt.collapsed ? induced_partition(cur.part, cur.N, M) : nxt.part;
+                for (size_t i = 0; i < p->local.size(); ++i) {
+                    const int r = p->local[i];
+                    SlabFusion sf;
+                    sf.fine_w = window_of(cur.part, r);
+                    sf.M = M;
+                    if (nxt.collapsed) {  // every rank writes its rows of a full coarse array
+                        sf.Fc = p->stage[i];
+                        sf.fc_w = RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]};
+                    } else {
+                        sf.Fc = nxt.loc[i].F;
+                        sf.fc_w = window_of(nxt.part, r);
+                    }
+                    // U starts from zero on every descent (:252-257; a restart inside one file is
+                    // not supported in slab mode), so no U ghost exchange is needed here
+                    slab_smooth(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
+                }
+                if (nxt.collapsed) {
+                    if (is_root_local(p) || p->real) gather_to_root(p, cpart, M, is_root_local(p) ? nxt.loc[0].F : nullptr);
+                } else {
+                    p->levels.push_back(nxt);
+                    exchange_ghosts(p, p->levels.back(), ARR_F);
+                    continue;
+                }
+            }
+            p->levels.push_back(nxt);
+        } else if (node == 0) {  // :305-324
+            double tol, opt;
+            if (!next(&tol) || !next(&opt)) { p->status = 3; break; }
+            Level &cur = p->levels.back();
+            if (!cur.collapsed) { p->status = 12; break; }  // the exact solver runs on the root only
+            if ((int)opt != 1) { p->status = 5; break; }
+            add_record(p, 0, cur.N, 0, 1);
+            if (is_root_local(p)) mg_doExactSolver(cur.N, p->L, cur.loc[0].U, cur.loc[0].F, tol, 1);
+        } else if (node == 1) {  // prolong + add + smooth, :329-424
+            --at;
+            if (p->levels.size() < 2) { p->status = 6; break; }
+            Level coarse = p->levels.back();
+            p->levels.pop_back();
+            Level &fine = p->levels.back();
+            if ((int)p->records.size() >= (int)p->max_rec) { p->status = 11; break; }
+            if (fine.collapsed) {
+                const int rec = add_record(p, 1, fine.N, step, 1);
+                if (is_root_local(p)) {
+                    mg_prolong_smooth(coarse.N, coarse.loc[0].U, fine.N, p->L, fine.loc[0].U, fine.loc[0].D, fine.loc[0].F,
+                                      step, raw_slot(p, (size_t)rec, 0));
+                    std::swap(fine.loc[0].U, fine.loc[0].D);
+                }
+            } else {
+                const int rec = add_record(p, 1, fine.N, step, 0);
+                if (coarse.collapsed) broadcast_from_root(p, coarse.N, is_root_local(p) ? coarse.loc[0].U : nullptr);
+                else exchange_ghosts(p, coarse, ARR_U);
+                exchange_ghosts(p, fine, ARR_U);
+                for (size_t i = 0; i < p->local.size(); ++i) {
+                    const int r = p->local[i];
+                    SlabFusion sf;
+                    sf.fine_w = window_of(fine.part, r);
+                    sf.Nc = coarse.N;
+                    if (coarse.collapsed) {
+                        sf.coarse = p->stage[i];
+                        sf.coarse_w = RowWindow{0, coarse.N, 0, coarse.N};
+                    } else {
+                        sf.coarse = coarse.loc[i].U;
+                        sf.coarse_w = window_of(coarse.part, r);
+                    }
+                    slab_smooth(fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
+                    std::swap(fine.loc[i].U, fine.loc[i].D);
+                }
+            }
+            free_level(p, coarse);
+            if (p->levels.size() == 1) came_back_up = true;
+        }
+    }
+    flush_norms();
+    c.defer_norms = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+// host-only: the row ranges each rank owns on every level of the hierarchy a cycle file
+// generates (N_max, halving down to N_min), and which levels are collapsed onto rank 0.
+// out[(level*nranks + rank)*2 + {0,1}] = {lo, hi}; collapsed levels report {0, N} for rank 0
+// and {0, 0} for the others.  Returns the number of levels.
+int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out)
+{
+    std::vector<int> sizes;
+    for (int n = N_max; n >= N_min && n > 0; n /= 2) sizes.push_back(n);
+    Partition cur = split_rows(N_max, nranks);
+    bool collapsed = false;
+    for (size_t l = 0; l < sizes.size(); ++l) {
+        const int N = sizes[l];
+        if (l > 0 && !collapsed) {
+            Partition nx = induced_partition(cur, sizes[l - 1], N);
+            if (N <= collapse_N || N % 2 != 0 || min_rows(nx) < 2 * GHOST) collapsed = true;
+            else cur = nx;
+        }
+        if (collapsed_out) collapsed_out[l] = collapsed ? 1 : 0;
+        for (int r = 0; r < nranks; ++r) {
+            if (out) {
+                out[(l * (size_t)nranks + r) * 2 + 0] = collapsed ? 0 : cur.lo[(size_t)r];
+                out[(l * (size_t)nranks + r) * 2 + 1] = collapsed ? (r == 0 ? N : 0) : cur.hi[(size_t)r];
+            }
+        }
+    }
+    return (int)sizes.size();
+}
+
+int mg_slab_ghost_rows(void) { return GHOST; }
+
+// rank >= 0: this process is that rank (RCCL communicator from mg_comm_init must exist when
+// nranks > 1).  rank == -1: all nranks slabs live in this process (virtual ranks).
+mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N)
+{
+    if (!require_ready("mg_slab_load")) return nullptr;
+    std::ifstream f(path);
+    if (!f.is_open()) {
+        fail(MG_ERR_CYCLE_FILE, "Cannot open file %s", path);
+        return nullptr;
+    }
+    mg_slab_plan *p = new mg_slab_plan;
+    p->path = path;
+    if (!(f >> p->L >> p->min_x >> p->min_y >> p->con_step >> p->con_N >> p->N_max >> p->N_min)) {
+        fail(MG_ERR_CYCLE_FILE, "%s: malformed cycle structure header", path);
+        delete p;
+        return nullptr;
+    }
+    if (p->con_N != 1 || p->con_step < 1 || p->con_step > k::stream_max_steps() || p->N_max % 2 != 0) {
+        fail(MG_ERR_UNSUPPORTED,
+             "row-slab mode needs con_N = 1, a fixed con_step in 1..%d and an even N_max (got con_step=%d con_N=%d N_max=%d)",
+             k::stream_max_steps(), p->con_step, p->con_N, p->N_max);
+        delete p;
+        return nullptr;
+    }
+    if (nranks < 1 || rank >= nranks || (rank >= 0 && nranks > 1 && (!comm_ready() || comm_size() != nranks || comm_rank() != rank))) {
+        fail(MG_ERR_COMM, "mg_slab_load: rank %d of %d without a matching communicator (mg_comm_init)", rank, nranks);
+        delete p;
+        return nullptr;
+    }
+    std::string tk;
+    while (f >> tk) {
+        char *end = nullptr;
+        const double v = strtod(tk.c_str(), &end);
+        if (end == tk.c_str()) break;
+        p->tokens.push_back(v);
+    }
+    for (int n = p->N_max; n >= p->N_min && n > 0; n /= 2) p->sizes.push_back(n);
+    p->nranks = nranks;
+    p->real = rank >= 0 && nranks > 1;
+    if (rank >= 0) p->local.push_back(rank);
+    else for (int r = 0; r < nranks; ++r) p->local.push_back(r);
+    p->collapse_N = collapse_N;
+
+    // partitions of the whole hierarchy
+    const size_t nl = p->sizes.size();
+    std::vector<int> ranges(nl * (size_t)nranks * 2), coll(nl);
+    mg_slab_partition(p->N_max, p->N_min, nranks, collapse_N, ranges.data(), coll.data());
+    p->parts.resize(nl);
+    p->level_collapsed.resize(nl);
+    for (size_t l = 0; l < nl; ++l) {
+        p->level_collapsed[l] = coll[l] != 0;
+        for (int r = 0; r < nranks; ++r) {
+            p->parts[l].lo.push_back(ranges[(l * (size_t)nranks + r) * 2]);
+            p->parts[l].hi.push_back(ranges[(l * (size_t)nranks + r) * 2 + 1]);
+        }
+    }
+    if (p->level_collapsed[0] || min_rows(p->parts[0]) < 2 * GHOST) {
+        fail(MG_ERR_UNSUPPORTED, "row-slab mode: N_max=%d is too small for %d ranks", p->N_max, nranks);
+        delete p;
+        return nullptr;
+    }
+    // a full coarse array per local rank for the collapse boundary
+    size_t stage_n = 0;
+    for (size_t l = 1; l < nl; ++l)
+        if (p->level_collapsed[l] && !p->level_collapsed[l - 1]) stage_n = (size_t)p->sizes[l] * p->sizes[l];
+    for (size_t i = 0; i < p->local.size(); ++i) p->stage.push_back(stage_n ? (double *)p->pool.get(stage_n * sizeof(double)) : nullptr);
+
+    size_t smoothing_nodes = 0;
+    for (double t : p->tokens)
+        if (t == -1.0 || t == 1.0 || t == 0.0) ++smoothing_nodes;
+    p->max_rec = smoothing_nodes + 8;
+    p->raw_dev = (double *)p->pool.get((p->max_rec + 1) * p->local.size() * sizeof(double));
+    if (p->real) p->all_dev = (double *)p->pool.get((p->max_rec + 1) * (size_t)nranks * sizeof(double));
+
+    // finest level: every rank evaluates getSource on its own window (:153)
+    Level top;
+    top.N = p->N_max;
+    top.part = p->parts[0];
+    alloc_level(p, top);
+    for (size_t i = 0; i < p->local.size(); ++i) {
+        const RowWindow w = window_of(top.part, p->local[i]);
+        const int lo = std::max(0, w.base), hi = std::min(top.N, w.base + w.rows);
+        fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(top.loc[i].F, w, top.N, lo));
+    }
+    p->levels.push_back(top);
+    (void)hipEventCreate(&p->ev0);
+    (void)hipEventCreate(&p->ev1);
+    mg_sync();
+    return p;
+}
+
+int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_slab_execute") || !p) return 1;
+    Context &c = ctx();
+    memset(out, 0, sizeof *out);
+    while (p->levels.size() > 1) {
+        free_level(p, p->levels.back());
+        p->levels.pop_back();
+    }
+    p->records.clear();
+    p->rec_final.clear();
+    p->status = 0;
+    c.active_pool = &p->pool;
+    (void)hipMemsetAsync(p->raw_dev, 0, (p->max_rec + 1) * p->local.size() * sizeof(double), c.stream);
+    mg_sync();
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipEventRecord(p->ev0, c.stream);
+    run(p);
+    (void)hipEventRecord(p->ev1, c.stream);
+    mg_sync();
+    const auto t1 = std::chrono::steady_clock::now();
+    c.active_pool = nullptr;
+    float dev_ms = 0.f;
+    (void)hipEventElapsedTime(&dev_ms, p->ev0, p->ev1);
+
+    // outside the window: the analytic error (:434-445) and the smoothing errors, combined
+    // over the slabs in rank order
+    Level &top = p->levels[0];
+    const size_t nloc = p->local.size(), nrec = p->records.size();
+    for (size_t i = 0; i < nloc; ++i)
+        k::analytic_error_rows(c.stream, top.N, p->L, top.loc[i].U, window_of(top.part, p->local[i]), p->min_x, p->min_y,
+                               raw_slot(p, p->max_rec, i));
+    std::vector<double> raw((p->max_rec + 1) * (size_t)p->nranks, 0.0);  // [slot][global rank]
+    if (p->real) {
+        comm_allgather(p->raw_dev, p->all_dev, p->max_rec + 1);  // nloc == 1: [slot] per rank
+        std::vector<double> tmp((p->max_rec + 1) * (size_t)p->nranks);
+        mg_download(tmp.data(), p->all_dev, tmp.size());
+        for (int r = 0; r < p->nranks; ++r)
+            for (size_t s = 0; s <= p->max_rec; ++s) raw[s * (size_t)p->nranks + r] = tmp[(size_t)r * (p->max_rec + 1) + s];
+    } else {
+        mg_download(raw.data(), p->raw_dev, raw.size());
+    }
+    for (size_t k2 = 0; k2 < nrec; ++k2) {
+        mg_node_record &rec = p->records[k2];
+        if (rec.node == 0) continue;
+        if (p->rec_final[k2]) {
+            rec.error = raw[k2 * (size_t)p->nranks + 0];
+            continue;
+        }
+        double s = 0.0;
+        for (int r = 0; r < p->nranks; ++r) s += raw[k2 * (size_t)p->nranks + r];
+        double e = s + s;  // :621-622
+        e = e / rec.N / rec.N;
+        rec.error = e;
+    }
+    double a = 0.0;
+    for (int r = 0; r < p->nranks; ++r) a += raw[p->max_rec * (size_t)p->nranks + r];
+
+    out->status = p->status ? p->status : (c.last_error ? 10 : 0);
+    out->N = top.N;
+    out->U_dev = nullptr;
+    out->mg_error = a / (double)(top.N * top.N);
+    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->device_ms = dev_ms;
+    out->n_records = (int)nrec;
+    out->records = p->records.data();
+    out->report = "";
+    return out->status;
+}
+
+// the owned rows of this process's slabs of the finest U, into a full N x N host array
+int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
+{
+    if (!require_ready("mg_slab_gather_U") || !p) return 1;
+    Level &top = p->levels[0];
+    for (size_t i = 0; i < p->local.size(); ++i) {
+        const RowWindow w = window_of(top.part, p->local[i]);
+        mg_download(host_full + (size_t)w.own_lo * top.N, row_ptr(top.loc[i].U, w, top.N, w.own_lo),
+                    (size_t)(w.own_hi - w.own_lo) * top.N);
+    }
+    return 0;
+}
+
+void mg_slab_destroy(mg_slab_plan *p)
+{
+    if (!p) return;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    for (Level &lv : p->levels) free_level(p, lv);
+    p->levels.clear();
+    for (double *s : p->stage)
+        if (s) p->pool.put(s);
+    if (p->raw_dev) p->pool.put(p->raw_dev);
+    if (p->all_dev) p->pool.put(p->all_dev);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    p->pool.trim();
+    delete p;
+}
+
+}  // extern "C"

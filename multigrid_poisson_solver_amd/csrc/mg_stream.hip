@@ -65,6 +65,13 @@ struct StreamParams {
     int rows_per_chunk;
     int groups;         // workgroups per chunk row
     int n_blocks;       // chunks * groups
+    // row window (1-D row-slab decomposition): the fine arrays in/F/out/D start at global
+    // row row_base and hold rows_local rows; this launch updates rows [own_y0, own_y1).
+    // Single GPU: row_base = 0, rows_local = N, own = [0, N).
+    int row_base, rows_local, own_y0, own_y1;
+    int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
+    int raw_norm;                   // error output is the raw sum over the owned rows
+    int fc_base, fc_rows;           // RESTRICT: window of Fc (global row of its first local row, rows)
     // IN_PROLONG: coarse grid and the host-built tables of doProlongation
     const double *coarse;
     int Nc;
@@ -168,12 +175,15 @@ struct Halo {
 struct Coarse3 {
     double v[3];
 };
-__device__ __forceinline__ Coarse3 load_coarse(const double *__restrict__ coarse, int Nc, int row, int col, bool ok)
+__device__ __forceinline__ Coarse3 load_coarse(const double *__restrict__ coarse, int Nc, int base, int rows, int row,
+                                               int col, bool ok)
 {
     Coarse3 c;
     c.v[0] = c.v[1] = c.v[2] = 0.0;
     if (ok) {
-        const int r = row < Nc - 1 ? row : Nc - 1;
+        // rows fetched ahead of need may lie past the local window: clamp (never consumed)
+        int r = row - base;
+        r = r < 0 ? 0 : (r < rows - 1 ? r : rows - 1);
         const double *b = coarse + (size_t)r * Nc;
         c.v[0] = b[col];
         c.v[1] = b[col + 1 < Nc ? col + 1 : Nc - 1];
@@ -207,10 +217,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         if (p.part && lane == 0) p.part[(size_t)tile * WAVES_PER_WG + wave] = 0.0;
         return;
     }
-    const int y0 = chunk * p.rows_per_chunk;
+    const int y0 = p.own_y0 + chunk * p.rows_per_chunk;
     int y1 = y0 + p.rows_per_chunk;
-    if (y1 > N) y1 = N;
-    if (y0 >= N) return;
+    if (y1 > p.own_y1) y1 = p.own_y1;
+    if (y0 >= p.own_y1) return;
+    // rows that exist in the local window and in the grid
+    const int av_lo = p.row_base > 0 ? p.row_base : 0;
+    const int av_hi = p.row_base + p.rows_local < N ? p.row_base + p.rows_local : N;
 
     const int xl = own_x0 - H + lane * COLS;  // this lane's first column
     bool col_in[COLS], col_edge[COLS], col_even[COLS];
@@ -290,9 +303,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int y = y_first + k;
-        const bool row_ok = y >= 0 && y < N && y < y_end;
+        const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
         const bool ok = lane_loads && row_ok;
-        const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
+        const size_t off = (size_t)(row_ok ? y - p.row_base : 0) * N + col_off;
         if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
         pf[k] = load_row<COLS>(p.F + off, ok);
         q_own[k] = -1;
@@ -333,9 +346,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             const double rc_w = q_rw[k];
             {   // refill this FIFO slot with the row PF ahead
                 const int y = yin + PF;
-                const bool row_ok = y >= 0 && y < N && y < y_end;
+                const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
                 const bool ok = lane_loads && row_ok;
-                const size_t off = (size_t)(y < 0 ? 0 : y) * N + col_off;
+                const size_t off = (size_t)(row_ok ? y - p.row_base : 0) * N + col_off;
                 if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
                 pf[k] = load_row<COLS>(p.F + off, ok);
                 if constexpr (IN == IN_PROLONG) {
@@ -366,11 +379,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                             c_hi = c_n1;
                             c_n1 = c_n2;
                         } else {                   // first row of the chunk (or a jump)
-                            c_lo = load_coarse(p.coarse, p.Nc, own_i, pc_base, lane_loads);
-                            c_hi = load_coarse(p.coarse, p.Nc, own_i + 1, pc_base, lane_loads);
-                            c_n1 = load_coarse(p.coarse, p.Nc, own_i + 2, pc_base, lane_loads);
+                            c_lo = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i, pc_base, lane_loads);
+                            c_hi = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 1, pc_base, lane_loads);
+                            c_n1 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 2, pc_base, lane_loads);
                         }
-                        c_n2 = load_coarse(p.coarse, p.Nc, own_i + 3, pc_base, lane_loads);  // two coarse rows ahead
+                        c_n2 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 3, pc_base, lane_loads);  // two coarse rows ahead
                         c_row = own_i;
                     }
                     const double c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // nw is level S of row yin-S: the smoothed U
             {
                 const int y = yin - S;
-                if (y >= y0 && y < y1 && lane_owns) store_row<COLS>(p.out + (size_t)y * N + xl, nw);
+                if (y >= y0 && y < y1 && lane_owns) store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw);
             }
 
             // residual stage, row yin-S-1 (src/MG_solver_CPU.cpp:560 and the error sums :611)
@@ -440,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     // (row+col) even interior points only, :610/:617
                     if (mine && interior && (((y & 1) == 0) == col_even[j])) acc += fabs(r);
                 }
-                if (mine && p.D) store_row<COLS>(p.D + (size_t)y * N + xl, d);
+                if (mine && p.D) store_row<COLS>(p.D + (size_t)(y - p.row_base) * N + xl, d);
 
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                             const double u3 = rc_shift ? q_up : d.v[1];
                             // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
                             const double vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
-                            if (rc_col >= 0) p.Fc[(size_t)rc_row * p.M + rc_col] = vc;
+                            if (rc_col >= 0) p.Fc[(size_t)(rc_row - p.fc_base) * p.M + rc_col] = vc;
                         }
                     }
                     d_prev = d;
@@ -477,14 +490,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 
 // rim of the next level's F: memset(U_c, 0) of doRestriction (:651) for the points the
 // fused restriction never writes
-__global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc)
+__global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc, int base, int rows)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    Uc[i] = 0.0;
-    Uc[(size_t)(M - 1) * M + i] = 0.0;
-    Uc[(size_t)i * M] = 0.0;
-    Uc[(size_t)i * M + M - 1] = 0.0;
+    if (i < M) {  // first and last grid row, where the local window holds them
+        if (base <= 0 && base + rows > 0) Uc[(size_t)(0 - base) * M + i] = 0.0;
+        if (base <= M - 1 && base + rows > M - 1) Uc[(size_t)(M - 1 - base) * M + i] = 0.0;
+    }
+    if (i < rows) {  // first and last column of every local row that lies in the grid
+        const int g = base + i;
+        if (g >= 0 && g < M) {
+            Uc[(size_t)i * M] = 0.0;
+            Uc[(size_t)i * M + M - 1] = 0.0;
+        }
+    }
 }
 
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
@@ -503,16 +522,18 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         blocks_per_cu = n > 8 ? 8 : n;
     }
     const int N = p.N;
+    const int own = p.own_y1 - p.own_y0;  // rows this launch updates (N on a single GPU)
+    if (own <= 0) return;
     constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT>::value;
     const int strips = (N + OW - 1) / OW;
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     const int resident = ctx().n_cu * blocks_per_cu;
     int chunks = resident / groups;
-    const int max_chunks = (N + 7) / 8;  // small grids: parallelism over halo economy
+    const int max_chunks = (own + 7) / 8;  // small grids: parallelism over halo economy
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
-    const int rows = (N + chunks - 1) / chunks;
-    chunks = (N + rows - 1) / rows;
+    const int rows = (own + chunks - 1) / chunks;
+    chunks = (own + rows - 1) / rows;
     p.rows_per_chunk = rows;
     p.groups = groups;
     p.n_blocks = chunks * groups;
@@ -522,10 +543,14 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         p.part = norm_partials(n_part);  // every wave of every tile writes its slot
         if (!p.part) return;
     }
-    if (RESTRICT) hipLaunchKernelGGL(k_zero_rim, dim3((p.M + 255) / 256), dim3(256), 0, s, p.M, p.Fc);
+    if (RESTRICT) {
+        const int span = p.M > p.fc_rows ? p.M : p.fc_rows;
+        hipLaunchKernelGGL(k_zero_rim, dim3((span + 255) / 256), dim3(256), 0, s, p.M, p.Fc, p.fc_base, p.fc_rows);
+    }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
     hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
-    if (err_out) norm_finish(s, p.part, n_part, N, err_out);
+    // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
+    if (err_out) norm_finish(s, p.part, n_part, p.raw_norm ? -1 : N, err_out);
 }
 
 template <int S>
@@ -554,7 +579,8 @@ bool stream_fusable(int N) { return N >= 4 && N % 2 == 0; }
 
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out,
                    int steps, double *err_out, double *D_out, int d_sign, const double *coarse, int Nc,
-                   const ProlongTable *pt, double *Fc, int M, const RestrictTable *rt)
+                   const ProlongTable *pt, double *Fc, int M, const RestrictTable *rt, const RowWindow *fine_w,
+                   const RowWindow *coarse_w, const RowWindow *fc_w)
 {
     if (steps < 1 || steps > MAX_S) {
         fail(MG_ERR_ARG, "jacobi_stream: %d sweeps per launch (1..%d)", steps, MAX_S);
@@ -573,7 +599,14 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
     p.out = out;
     p.D = D_out;
     p.d_sign = d_sign;
+    p.row_base = fine_w ? fine_w->base : 0;
+    p.rows_local = fine_w ? fine_w->rows : N;
+    p.own_y0 = fine_w ? fine_w->own_lo : 0;
+    p.own_y1 = fine_w ? fine_w->own_hi : N;
+    p.raw_norm = fine_w ? 1 : 0;
     if (coarse) {
+        p.coarse_base = coarse_w ? coarse_w->base : 0;
+        p.coarse_rows = coarse_w ? coarse_w->rows : Nc;
         p.coarse = coarse;
         p.Nc = Nc;
         p.p_orow = pt->owner_row;
@@ -586,6 +619,8 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
         p.c_dx_rcp = 1.0 / pt->c_dx;  // IEEE division on the host: correctly rounded
     }
     if (Fc) {
+        p.fc_base = fc_w ? fc_w->base : 0;
+        p.fc_rows = fc_w ? fc_w->rows : M;
         p.Fc = Fc;
         p.M = M;
         p.r_inv = rt->inv;

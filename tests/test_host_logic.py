@@ -56,8 +56,9 @@ def test_dropin_header_names_match_reference_surface():
 def test_no_cpu_fallback_without_gpu(m):
     """On a machine without a HIP device mg_init must fail loudly and every operator must
     refuse to run (the product path never routes through a CPU implementation)."""
-    import torch
-    if torch.cuda.is_available():
+    # (not torch.cuda.is_available(): importing torch AFTER libmgpoisson.so would load a second
+    # HIP runtime next to the one the engine is linked against)
+    if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present")
     code = ("import multigrid_poisson_solver_amd as m\n"
             "try:\n    m.init(0)\nexcept m.MGError as e:\n    print('REFUSED', e)\n"

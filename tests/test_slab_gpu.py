@@ -1,0 +1,90 @@
+"""The 1-D row-slab decomposition, verified bit for bit on ONE GPU with virtual ranks: all R
+slabs live in this process and exchange ghost rows by device copies (mg_slab_load rank=-1).
+The same driver code runs one rank per process over RCCL under bench.py --gpus N; only the
+transport (mg_comm.cpp) differs."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def check(got, U, want):
+    assert got["status"] == 0 and want["status"] == 0
+    assert_bits(U, want["U"], "final U", zero_sign=True)
+    assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+    assert len(got["records"]) == len(want["records"])
+    for g, w in zip(got["records"], want["records"]):
+        assert tuple(g[:3]) == tuple(w[:3])
+        assert g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+
+
+@pytest.mark.parametrize("R", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("collapse", [64, 256])
+def test_virtual_slabs_vcycle_vs_oracle(mg, oracle, tmp_path, R, collapse):
+    N = 1024
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path)
+    plan = mg.SlabPlan(path, R, -1, collapse)
+    for _ in range(2):  # the second run reuses pooled buffers
+        got = plan.execute()
+        check(got, plan.gather_U(N), want)
+    plan.close()
+
+
+@pytest.mark.parametrize("R", [2, 5])
+def test_virtual_slabs_wcycle_and_other_steps(mg, oracle, tmp_path, R):
+    N = 512
+    w = str(tmp_path / "W.txt")
+    mg.write_wcycle_file(w, N, 8, 2, 1e-7)
+    want = oracle.run_cycle_file(w)
+    plan = mg.SlabPlan(w, R, -1, 64)
+    got = plan.execute()
+    check(got, plan.gather_U(N), want)
+    plan.close()
+    v = str(tmp_path / "V4.txt")
+    mg.write_vcycle_file(v, N, 16, 4, 1e-6)
+    want = oracle.run_cycle_file(v)
+    plan = mg.SlabPlan(v, R, -1, 128)
+    got = plan.execute()
+    check(got, plan.gather_U(N), want)
+    plan.close()
+
+
+def test_virtual_slabs_match_single_gpu_driver_at_4096(mg, tmp_path):
+    """8 slabs of a 4096^2 V-cycle against the single-GPU driver (itself pinned to the oracle)."""
+    N = 4096
+    path = str(tmp_path / "V4096.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    single = mg.CyclePlan(path, fused=True, report=False)
+    ref = single.execute(fetch_U=True)
+    plan = mg.SlabPlan(path, 8, -1, 512)
+    got = plan.execute()
+    assert_bits(plan.gather_U(N), ref["U"], "8 slabs vs 1 GPU", zero_sign=True)
+    assert got["mg_error"] == pytest.approx(ref["mg_error"], rel=1e-10)
+    for g, w in zip(got["records"], ref["records"]):
+        assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    plan.close(); single.close()
+
+
+def test_slab_mode_refuses_what_it_does_not_implement(mg, tmp_path):
+    trig = tmp_path / "trigger.txt"
+    trig.write_text("1.0 0.0 0.0\n-1 1\n256 8\n-1\n-1\n0\n0.0000001 1\n1\n1\n2")
+    with pytest.raises(mg.MGError, match="row-slab mode"):
+        mg.SlabPlan(str(trig), 2, -1, 64)
+    small = tmp_path / "small.txt"
+    small.write_text("1.0 0.0 0.0\n3 1\n32 8\n-1\n0\n0.0000001 1\n1\n2")
+    with pytest.raises(mg.MGError, match="too small"):
+        mg.SlabPlan(str(small), 8, -1, 8)
+
+
+def test_rccl_communicator_single_rank(mg):
+    """The transport itself cannot be exercised across ranks on a one-GPU box (RCCL refuses
+    two ranks on one device); a 1-rank communicator at least proves the library binding."""
+    uid = mg.comm_unique_id()
+    assert len(uid) == mg.lib().mg_comm_unique_id_bytes()
+    mg.comm_init(0, 1, uid)
+    assert mg.lib().mg_comm_rank() == 0 and mg.lib().mg_comm_size() == 1
+    mg.lib().mg_comm_finalize()
