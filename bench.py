@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--smoother", choices=["stream", "simple"], default=os.environ.get("MG_SMOOTHER", "stream"))
     ap.add_argument("--cpu-n", type=int, default=None, help="grid size of the CPU baseline sample (default: --n)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the row-slab/RCCL leg even with one rank (plumbing rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,7 +85,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_slab:
         import bench_multi  # row-slab path (one process per GPU, RCCL ghost rows)
         return bench_multi.run(args, rank, world, local_rank)
 

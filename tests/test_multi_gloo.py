@@ -1,0 +1,63 @@
+"""CPU coverage of the N > 1 path: world_size-2 (and 3) gloo runs of tests/_slab_worker.py.
+The worker runs in its own processes (it imports torch before the engine library; this
+pytest process never imports torch)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,N,collapse", [(2, 256, 32), (2, 128, 64), (3, 256, 64)])
+def test_row_slab_schedule_on_gloo(tmp_path, world, N, collapse):
+    import multigrid_poisson_solver_amd as mg
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "_slab_worker.py"), str(N), str(collapse), "3", path]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert f"SLAB_EMULATION OK {world} {N} {collapse}" in out.stdout
+
+
+def test_partition_properties():
+    """mg_slab_partition (host code of the product): contiguous cover of every distributed
+    level, every slab at least two halos tall, coarse rows owned where their lower-left
+    restriction sample lives."""
+    import multigrid_poisson_solver_amd as mg
+    G = mg.slab_ghost_rows()
+    assert G >= 6
+    for N, R, collapse in [(8192, 8, 1024), (23168, 8, 1024), (11584, 2, 1024), (1024, 3, 128), (16384, 4, 512)]:
+        levels = mg.slab_partition(N, 8, R, collapse)
+        seen_collapsed = False
+        for li, (n, collapsed, ranges) in enumerate(levels):
+            if collapsed:
+                seen_collapsed = True
+                assert ranges[0] == (0, n) and all(r == (0, 0) for r in ranges[1:])
+                continue
+            assert not seen_collapsed and n % 2 == 0 and n > collapse
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for a, b in zip(ranges[:-1], ranges[1:]):
+                assert a[1] == b[0]
+            assert min(hi - lo for lo, hi in ranges) >= 2 * G
+            if li > 0 and not levels[li - 1][1]:
+                fine = levels[li - 1][2]
+                lo_t, _ = mg.restriction_table(levels[li - 1][0], n)
+                for r, (clo, chi) in enumerate(ranges):
+                    for rc in (max(1, clo), min(n - 2, chi - 1)):
+                        assert fine[r][0] <= lo_t[rc] < fine[r][1]
