@@ -221,6 +221,8 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
 int  mg_slab_execute(mg_slab_plan *plan, mg_cycle_result *out);
 /* owned rows of this process's slabs of the finest U into a full N x N host array */
 int  mg_slab_gather_U(mg_slab_plan *plan, double *host_full);
+/* mg_error (src/MG_solver_CPU.cpp:434-445) is evaluated after each window unless turned off */
+void mg_slab_want_error(mg_slab_plan *plan, int on);
 void mg_slab_destroy(mg_slab_plan *plan);
 
 #ifdef __cplusplus

@@ -73,7 +73,7 @@ ABI = {
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
-    "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_destroy": (None, [_vp]),
+    "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
     "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
 }
 
@@ -461,6 +461,9 @@ class SlabPlan:
         return dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
                     records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
                              for i in range(res.n_records)])
+
+    def want_error(self, on):
+        _lib.mg_slab_want_error(self._plan, 1 if on else 0)
 
     def gather_U(self, N):
         U = np.zeros((N, N))

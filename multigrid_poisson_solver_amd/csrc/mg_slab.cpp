@@ -115,18 +115,12 @@ struct mg_slab_plan {
     size_t max_rec = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int status = 0;
+    int want_error = 1;   // evaluate the analytic error after the window (outside the timing)
 };
 
 namespace {
 
 bool is_root_local(const mg_slab_plan *p) { return p->local[0] == 0; }
-int local_index(const mg_slab_plan *p, int global_rank)
-{
-    for (size_t i = 0; i < p->local.size(); ++i)
-        if (p->local[i] == global_rank) return (int)i;
-    return -1;
-}
-
 RowWindow window_of(const Partition &part, int r)
 {
     RowWindow w;
@@ -530,7 +524,7 @@ int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
     // over the slabs in rank order
     Level &top = p->levels[0];
     const size_t nloc = p->local.size(), nrec = p->records.size();
-    for (size_t i = 0; i < nloc; ++i)
+    for (size_t i = 0; i < nloc && p->want_error; ++i)
         k::analytic_error_rows(c.stream, top.N, p->L, top.loc[i].U, window_of(top.part, p->local[i]), p->min_x, p->min_y,
                                raw_slot(p, p->max_rec, i));
     std::vector<double> raw((p->max_rec + 1) * (size_t)p->nranks, 0.0);  // [slot][global rank]
@@ -582,6 +576,11 @@ int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
                     (size_t)(w.own_hi - w.own_lo) * top.N);
     }
     return 0;
+}
+
+void mg_slab_want_error(mg_slab_plan *p, int on)
+{
+    if (p) p->want_error = on != 0;
 }
 
 void mg_slab_destroy(mg_slab_plan *p)
