@@ -18,8 +18,9 @@
 //   * strips overlap by H = S+1 columns (rounded up to even) and chunks by S+1 rows on
 //     each side: the halo is recomputed redundantly instead of exchanged (the overlap
 //     re-reads hit L2: the block index is remapped so neighbouring tiles share an XCD);
-//   * the next PF rows are always in flight (register FIFO, loop unrolled by PF) so a
-//     wave keeps 2*PF KiB of loads outstanding without relying on occupancy.
+//   * the next PF rows are always in flight (register FIFO of 2*PF slots, loop unrolled by
+//     2*PF; every load is unconditional -- out-of-window rows/columns are clamped -- so the
+//     compiler can count the loads in flight and waits with vmcnt(N), not vmcnt(0)).
 //
 // Two more stages can be fused into the same pass (COLS = 2 builds):
 //   * IN_PROLONG: level 0 of a row is U_in + doProlongation(coarse) (:354 + :368),
@@ -38,6 +39,8 @@
 // read U, read F, write U, write D = 32 B per point instead of 24*S + 24 + 8.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mg_internal.h"
 
 namespace mg {
@@ -45,7 +48,7 @@ namespace k {
 
 namespace {
 
-constexpr int PF = 4;            // rows of U and F in flight per lane
+constexpr int PF_DEFAULT = 2;    // rows of U and F in flight per lane (FIFO of 2*PF slots)
 constexpr int WAVES_PER_WG = 4;  // 4 adjacent strips of one chunk
 constexpr int MAX_S = 4;
 
@@ -86,21 +89,22 @@ struct StreamParams {
     const double *r_wf; // [N] r_w[r_inv[x]] by fine index (0 where r_inv < 0)
 };
 
-// value of the neighbouring lane (lane-1 / lane+1); lanes at the wave edge read 0
+// value of the neighbouring lane (lane-1 / lane+1); the lane at the wave edge reads 0
+// (bound_ctrl: no previous destination value has to be materialised)
 __device__ __forceinline__ double from_lane_below(double v)
 {
     union { double d; int i[2]; } a, r;
     a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x138, 0xf, 0xf, false);
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x138, 0xf, 0xf, true);
     return r.d;
 }
 __device__ __forceinline__ double from_lane_above(double v)
 {
     union { double d; int i[2]; } a, r;
     a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xf, 0xf, false);
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xf, 0xf, true);
     return r.d;
 }
 
@@ -132,20 +136,21 @@ struct Row {
     double v[COLS];
 };
 
+// Row loads are UNCONDITIONAL: rows and columns outside the window are clamped to a valid
+// address instead of being skipped.  What such a load returns is never consumed by a point
+// that is stored (a rim point keeps its value and never looks at its neighbours), and a load
+// that is always issued lets the compiler count the loads in flight: with predicated loads it
+// has to assume none was issued and waits for vmcnt(0) at every use.
 template <int COLS>
-__device__ __forceinline__ Row<COLS> load_row(const double *__restrict__ base, bool ok)
+__device__ __forceinline__ Row<COLS> load_row(const double *__restrict__ base)
 {
     Row<COLS> r;
-#pragma unroll
-    for (int j = 0; j < COLS; ++j) r.v[j] = 0.0;
-    if (ok) {
-        if constexpr (COLS == 2) {
-            const double2_t t = *reinterpret_cast<const double2_t *>(base);
-            r.v[0] = t.x;
-            r.v[1] = t.y;
-        } else {
-            r.v[0] = *base;
-        }
+    if constexpr (COLS == 2) {
+        const double2_t t = *reinterpret_cast<const double2_t *>(base);
+        r.v[0] = t.x;
+        r.v[1] = t.y;
+    } else {
+        r.v[0] = *base;
     }
     return r;
 }
@@ -176,23 +181,21 @@ struct Coarse3 {
     double v[3];
 };
 __device__ __forceinline__ Coarse3 load_coarse(const double *__restrict__ coarse, int Nc, int base, int rows, int row,
-                                               int col, bool ok)
+                                               int col)
 {
+    // unconditional like load_row: rows fetched ahead of need may lie outside the local window
+    // and columns past the grid are clamped (never consumed)
     Coarse3 c;
-    c.v[0] = c.v[1] = c.v[2] = 0.0;
-    if (ok) {
-        // rows fetched ahead of need may lie past the local window: clamp (never consumed)
-        int r = row - base;
-        r = r < 0 ? 0 : (r < rows - 1 ? r : rows - 1);
-        const double *b = coarse + (size_t)r * Nc;
-        c.v[0] = b[col];
-        c.v[1] = b[col + 1 < Nc ? col + 1 : Nc - 1];
-        c.v[2] = b[col + 2 < Nc ? col + 2 : Nc - 1];
-    }
+    int r = row - base;
+    r = r < 0 ? 0 : (r < rows - 1 ? r : rows - 1);
+    const double *b = coarse + (size_t)r * Nc;
+    c.v[0] = b[col];
+    c.v[1] = b[col + 1 < Nc ? col + 1 : Nc - 1];
+    c.v[2] = b[col + 2 < Nc ? col + 2 : Nc - 1];
     return c;
 }
 
-template <int S, int COLS, int IN, bool RESTRICT>
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         lane_owns = lane_owns && x >= own_x0 && x < own_x0 + OW && x < N;
     }
     const bool lane_loads = col_in[0] && col_in[COLS - 1];  // COLS == 2: N even, xl even
+    // does ANY lane of this wave hold a rim column (x <= 0 or x >= N-1)?  wave-uniform: only the
+    // first and last strips do, every other wave skips the per-point rim selects
+    const bool wave_has_rim_col = (own_x0 - H) <= 0 || (own_x0 - H + W - 1) >= N - 1;
 
     const double dx2 = p.dx2, inv = p.inv;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
@@ -245,8 +251,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     int pc_base = 0;              // coarse column of this lane's first fine column
     bool pc_second_shift = false; // second fine column belongs to the next coarse cell
     double pc_hi[2] = {0.0, 0.0}, pc_lo[2] = {0.0, 0.0};
-    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}}, c_n1 = {{0.0, 0.0, 0.0}}, c_n2 = {{0.0, 0.0, 0.0}};
-    int c_row = -0x40000000;      // coarse row held in c_lo (uniform); c_hi, c_n1, c_n2 = the next three
+    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}};
+    int c_row = -0x40000000;      // coarse row held in c_lo (wave-uniform); c_hi holds c_row + 1
     if constexpr (IN == IN_PROLONG) {
         if (lane_loads) {
             pc_base = p.p_ocol[xl];
@@ -291,32 +297,51 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const int y_first = y0 - (S + 1);                             // first input row
     const int T = (y1 - y0) + 2 * (S + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
     const int y_end = y_first + T;                                // one past the last input row
-    const size_t col_off = (size_t)(xl < 0 ? 0 : xl);
+    // clamped column of this lane's loads (lanes left/right of the grid re-read a valid pair)
+    const size_t col_off = (size_t)(xl < 0 ? 0 : (xl > N - COLS ? N - COLS : xl));
 
     // wave-uniform per-row table entries travel through the same FIFO as the rows they
     // belong to, so their (scalar) loads are issued PF iterations before use
-    Row<COLS> pu[PF], pf[PF];
-    int q_own[PF];                // IN_PROLONG: owner coarse row of the input row
-    double q_yh[PF], q_yl[PF];    // IN_PROLONG: its two row weights
-    int q_rc[PF];                 // RESTRICT: coarse row sampled at fine row (input row - S - 2)
-    double q_rw[PF];              // RESTRICT: its weight c
+    // The FIFO has 2*PF slots and the loop body covers 2*PF rows: a slot is refilled PF rows
+    // after it was consumed, so a load never targets a register whose old value is still live.
+    // (With PF slots the compiler resolves the loop-carried slots by register copies at the
+    // back edge, which read the in-flight loads and force s_waitcnt vmcnt(0) every PF rows.)
+    constexpr int NB = 2 * PF;
+    Row<COLS> pu[NB], pf[NB];
+    Coarse3 pc[NB];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
+    int q_own[NB];                // IN_PROLONG: owner coarse row of the input row
+    double q_yh[NB], q_yl[NB];    // IN_PROLONG: its two row weights
+    int q_rc[NB];                 // RESTRICT: coarse row sampled at fine row (input row - S - 2)
+    double q_rw[NB];              // RESTRICT: its weight c
+#pragma unroll
+    for (int k = PF; k < NB; ++k) {
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) pu[k].v[j] = pf[k].v[j] = 0.0;
+        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
+        q_own[k] = q_rc[k] = -1;
+        q_yh[k] = q_yl[k] = q_rw[k] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int y = y_first + k;
         const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
-        const bool ok = lane_loads && row_ok;
-        const size_t off = (size_t)(row_ok ? y - p.row_base : 0) * N + col_off;
-        if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
-        pf[k] = load_row<COLS>(p.F + off, ok);
+        const int yc = y < av_lo ? av_lo : (y < av_hi ? y : av_hi - 1);  // clamped into the window
+        const size_t off = (size_t)(yc - p.row_base) * N + col_off;
+        if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off);
+        pf[k] = load_row<COLS>(p.F + off);
         q_own[k] = -1;
         q_yh[k] = q_yl[k] = q_rw[k] = 0.0;
         q_rc[k] = -1;
+        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
         if constexpr (IN == IN_PROLONG) {
             if (row_ok) {
                 q_own[k] = table_i(p.p_orow, y);
                 q_yh[k] = table_d(p.p_rhi, y);
                 q_yl[k] = table_d(p.p_rlo, y);
             }
+            // the UPPER coarse row of this input row travels with it through the FIFO, so every
+            // vector load of the loop is issued at a fixed place PF iterations before its use
+            pc[k] = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, q_own[k] + 1, pc_base);
         }
         if constexpr (RESTRICT) {
             const int yl = y - S - 2;
@@ -327,11 +352,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         }
     }
 
+    if constexpr (IN == IN_PROLONG) {
+        // before the first rotation c_hi must hold the owner row of the first input row
+        const int ys = y_first > av_lo ? y_first : av_lo;
+        if (ys < av_hi && ys < y_end) {
+            const int i0 = table_i(p.p_orow, ys);
+            c_hi = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_base);
+            c_row = i0 - 1;
+        }
+    }
+
     double acc = 0.0;
 
-    for (int t0 = 0; t0 < T; t0 += PF) {
+    for (int t0 = 0; t0 < T; t0 += NB) {
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
+        for (int k = 0; k < NB; ++k) {
+            const int kr = (k + PF) % NB;   // the slot refilled while slot k is consumed
             const int yin = y_first + t0 + k;
             Row<COLS> nw, cf = pf[k];
             if constexpr (IN == IN_ZERO) {
@@ -342,29 +378,31 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             }
             const int own_i = q_own[k];
             const double own_yh = q_yh[k], own_yl = q_yl[k];
+            const Coarse3 own_up = pc[k];
             const int rc_row = q_rc[k];
             const double rc_w = q_rw[k];
-            {   // refill this FIFO slot with the row PF ahead
+            {   // refill the slot consumed PF rows ago with the row PF ahead
                 const int y = yin + PF;
                 const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
-                const bool ok = lane_loads && row_ok;
-                const size_t off = (size_t)(row_ok ? y - p.row_base : 0) * N + col_off;
-                if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off, ok);
-                pf[k] = load_row<COLS>(p.F + off, ok);
+                const int yc = y < av_lo ? av_lo : (y < av_hi ? y : av_hi - 1);
+                const size_t off = (size_t)(yc - p.row_base) * N + col_off;
+                if constexpr (IN != IN_ZERO) pu[kr] = load_row<COLS>(p.in + off);
+                pf[kr] = load_row<COLS>(p.F + off);
                 if constexpr (IN == IN_PROLONG) {
-                    q_own[k] = -1;
+                    q_own[kr] = -1;
                     if (row_ok) {
-                        q_own[k] = table_i(p.p_orow, y);
-                        q_yh[k] = table_d(p.p_rhi, y);
-                        q_yl[k] = table_d(p.p_rlo, y);
+                        q_own[kr] = table_i(p.p_orow, y);
+                        q_yh[kr] = table_d(p.p_rhi, y);
+                        q_yl[kr] = table_d(p.p_rlo, y);
                     }
+                    pc[kr] = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, q_own[kr] + 1, pc_base);
                 }
                 if constexpr (RESTRICT) {
                     const int yl = y - S - 2;
-                    q_rc[k] = -1;
+                    q_rc[kr] = -1;
                     if (yl >= y0 && yl < y1) {
-                        q_rc[k] = table_i(p.r_inv, yl);
-                        q_rw[k] = table_d(p.r_wf, yl);
+                        q_rc[kr] = table_i(p.r_inv, yl);
+                        q_rw[kr] = table_d(p.r_wf, yl);
                     }
                 }
             }
@@ -373,19 +411,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 // level 0 = U + P(coarse): doProlongation :700 as a gather, then
                 // doGridAddition :569 (U1 = U1 + U2).  own_i is wave-uniform.
                 if (own_i >= 0) {
-                    if (own_i != c_row) {
-                        if (own_i == c_row + 1) {  // the owner row advanced by one: rotate
-                            c_lo = c_hi;
-                            c_hi = c_n1;
-                            c_n1 = c_n2;
-                        } else {                   // first row of the chunk (or a jump)
-                            c_lo = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i, pc_base, lane_loads);
-                            c_hi = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 1, pc_base, lane_loads);
-                            c_n1 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 2, pc_base, lane_loads);
-                        }
-                        c_n2 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, own_i + 3, pc_base, lane_loads);  // two coarse rows ahead
+                    if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
+                        c_lo = c_hi;
                         c_row = own_i;
                     }
+                    c_hi = own_up;         // row own_i + 1, loaded PF iterations ago
                     const double c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
 #pragma unroll
                     for (int j = 0; j < COLS; ++j) {
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                         const double xh = pc_hi[j], xlo = pc_lo[j];
                         const double num = (c1 * xh + c2 * xlo) * own_yh + (c3 * xh + c4 * xlo) * own_yl;
                         const double pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
-                        nw.v[j] = lane_loads ? nw.v[j] + pv : 0.0;
+                        nw.v[j] = nw.v[j] + pv;
                     }
                 }
             }
@@ -419,8 +449,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const double e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
                     // src/MG_solver_CPU.cpp:590: U += 0.25*(U[i+1]+U[i-1]+U[j+1]+U[j-1] - 4U - dx^2 F)
                     const double t = nw.v[j] + so.v[j] + e + w - 4 * c.v[j] - dx2 * fq[l].v[j];
-                    const double u = c.v[j] + 0.25 * t;
-                    o.v[j] = (row_edge || col_edge[j]) ? c.v[j] : u;
+                    o.v[j] = c.v[j] + 0.25 * t;
+                }
+                if (row_edge) {  // wave-uniform, two rows of the whole grid: the rim keeps its value
+                    o = c;
+                } else if (wave_has_rim_col) {  // wave-uniform, two strips of the whole grid
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) o.v[j] = col_edge[j] ? c.v[j] : o.v[j];
                 }
                 older[l - 1] = c;
                 newer[l - 1] = nw;
@@ -509,13 +544,13 @@ __global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
 // this instantiation x CUs) where the grid is large enough, never fewer than 8 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
-template <int S, int COLS, int IN, bool RESTRICT>
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
 void launch_k(hipStream_t s, StreamParams p, double *err_out)
 {
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT, PF>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -548,27 +583,36 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         hipLaunchKernelGGL(k_zero_rim, dim3((span + 255) / 256), dim3(256), 0, s, p.M, p.Fc, p.fc_base, p.fc_rows);
     }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
     // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
     if (err_out) norm_finish(s, p.part, n_part, p.raw_norm ? -1 : N, err_out);
+}
+
+template <int S, int PF>
+void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
+{
+    const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
+    if (p.N % 2 != 0) {  // 8 B lanes: odd row pitch; the fused transfer stages are not built for it
+        if (zero) launch_k<S, 1, IN_ZERO, false, PF>(s, p, err_out);
+        else launch_k<S, 1, IN_LOAD, false, PF>(s, p, err_out);
+    } else if (restrict_out) {
+        if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
+        else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
+    } else if (prolong_in) {
+        launch_k<S, 2, IN_PROLONG, false, PF>(s, p, err_out);
+    } else {
+        if (zero) launch_k<S, 2, IN_ZERO, false, PF>(s, p, err_out);
+        else launch_k<S, 2, IN_LOAD, false, PF>(s, p, err_out);
+    }
 }
 
 template <int S>
 void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
-    const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
-    if (p.N % 2 != 0) {  // 8 B lanes: odd row pitch; the fused transfer stages are not built for it
-        if (zero) launch_k<S, 1, IN_ZERO, false>(s, p, err_out);
-        else launch_k<S, 1, IN_LOAD, false>(s, p, err_out);
-    } else if (restrict_out) {
-        if (zero) launch_k<S, 2, IN_ZERO, true>(s, p, err_out);
-        else launch_k<S, 2, IN_LOAD, true>(s, p, err_out);
-    } else if (prolong_in) {
-        launch_k<S, 2, IN_PROLONG, false>(s, p, err_out);
-    } else {
-        if (zero) launch_k<S, 2, IN_ZERO, false>(s, p, err_out);
-        else launch_k<S, 2, IN_LOAD, false>(s, p, err_out);
-    }
+    // rows in flight per lane: registers (occupancy) against prefetch depth.  MG_PF=2|4.
+    static const int pf = [] { const char *e = getenv("MG_PF"); return e ? atoi(e) : PF_DEFAULT; }();
+    if (pf == 2) launch_variant<S, 2>(s, p, err_out);
+    else launch_variant<S, 4>(s, p, err_out);
 }
 
 }  // namespace

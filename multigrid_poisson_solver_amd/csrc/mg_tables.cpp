@@ -142,7 +142,7 @@ const ProlongTable &prolong_table(int N, int M)
         if (orow[k] > N - 2 || ocol[k] > N - 2) ok = false;
         if (orow[k] < 0 || ocol[k] < 0) fusable = false;
         if (k > 0 && (ocol[k] - ocol[k - 1] < 0 || ocol[k] - ocol[k - 1] > 1)) fusable = false;
-        if (k > 0 && orow[k] < orow[k - 1]) fusable = false;
+        if (k > 0 && (orow[k] - orow[k - 1] < 0 || orow[k] - orow[k - 1] > 1)) fusable = false;
     }
     if (!ok) {
         fail(MG_ERR_ARG, "doProlongation: table for %d -> %d is out of bounds", N, M);
