@@ -282,6 +282,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             }
         }
     }
+    // the rim of the next level's F is zero (doRestriction's memset, :651): rim columns are
+    // written by the lanes that own fine columns 0 and N-1 alongside every coarse row, rim rows
+    // by the chunks that hold fine rows 0 and N-1
+    const bool first_col_lane = RESTRICT && lane_owns && xl == 0;
+    const bool last_col_lane = RESTRICT && lane_owns && xl + COLS == N;
+    if constexpr (RESTRICT) {
+        for (int edge = 0; edge < 2; ++edge) {
+            if (edge == 0 ? (y0 != 0) : (y1 != N)) continue;
+            double *row = p.Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
+            if (rc_col >= 0) row[rc_col] = 0.0;
+            if (first_col_lane) row[0] = 0.0;
+            if (last_col_lane) row[p.M - 1] = 0.0;
+        }
+    }
 
     // register state: two-row history per level, F delay line, prefetch FIFO
     Row<COLS> older[S + 1], newer[S + 1], fq[S + 2];
@@ -506,7 +520,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                             const double u3 = rc_shift ? q_up : d.v[1];
                             // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
                             const double vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
-                            if (rc_col >= 0) p.Fc[(size_t)(rc_row - p.fc_base) * p.M + rc_col] = vc;
+                            double *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
+                            if (rc_col >= 0) crow[rc_col] = vc;
+                            if (first_col_lane) crow[0] = 0.0;
+                            if (last_col_lane) crow[p.M - 1] = 0.0;
                         }
                     }
                     d_prev = d;
@@ -520,24 +537,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) p.part[(size_t)tile * WAVES_PER_WG + wave] = acc;
-    }
-}
-
-// rim of the next level's F: memset(U_c, 0) of doRestriction (:651) for the points the
-// fused restriction never writes
-__global__ __launch_bounds__(256) void k_zero_rim(int M, double *__restrict__ Uc, int base, int rows)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < M) {  // first and last grid row, where the local window holds them
-        if (base <= 0 && base + rows > 0) Uc[(size_t)(0 - base) * M + i] = 0.0;
-        if (base <= M - 1 && base + rows > M - 1) Uc[(size_t)(M - 1 - base) * M + i] = 0.0;
-    }
-    if (i < rows) {  // first and last column of every local row that lies in the grid
-        const int g = base + i;
-        if (g >= 0 && g < M) {
-            Uc[(size_t)i * M] = 0.0;
-            Uc[(size_t)i * M + M - 1] = 0.0;
-        }
     }
 }
 
@@ -578,10 +577,6 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         p.part = norm_partials(n_part);  // every wave of every tile writes its slot
         if (!p.part) return;
     }
-    if (RESTRICT) {
-        const int span = p.M > p.fc_rows ? p.M : p.fc_rows;
-        hipLaunchKernelGGL(k_zero_rim, dim3((span + 255) / 256), dim3(256), 0, s, p.M, p.Fc, p.fc_base, p.fc_rows);
-    }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
     hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
     // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
@@ -610,7 +605,10 @@ template <int S>
 void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
     // rows in flight per lane: registers (occupancy) against prefetch depth.  MG_PF=2|4.
-    static const int pf = [] { const char *e = getenv("MG_PF"); return e ? atoi(e) : PF_DEFAULT; }();
+    // Large grids fill the chip with waves: fewer registers (PF = 2) win.  Small grids are latency
+    // bound on one wave per SIMD: a deeper FIFO (PF = 4) covers the memory latency instead.
+    static const int forced = [] { const char *e = getenv("MG_PF"); return e ? atoi(e) : 0; }();
+    const int pf = forced ? forced : (p.N <= 2048 ? 4 : 2);
     if (pf == 2) launch_variant<S, 2>(s, p, err_out);
     else launch_variant<S, 4>(s, p, err_out);
 }
