@@ -252,6 +252,122 @@ void smooth_level(Exec &x, LevelNode *lv, int step, bool zero_start, bool want_D
     }
 }
 
+// The coarse tail: once a descent reaches a level with N <= TAIL_MAX_N, the slice of the node
+// stream that stays on that level and below (up to, not including, the `1` that leaves it)
+// runs as ONE launch with all those levels in LDS (mg_tail.hip).  Returns false -- and consumes
+// nothing -- whenever the slice is not of the supported shape; the nodes are then interpreted
+// one by one as usual.  Records and report items are emitted exactly as the per-node path does.
+bool try_tail(Exec &x)
+{
+    mg_cycle_plan *p = x.p;
+    LevelList &cycle = *p->levels;
+    static const bool disabled = getenv("MG_NO_TAIL") != nullptr;
+    if (disabled || p->con_N != 1 || p->con_step < 1) return false;
+    LevelNode *top = cycle.last();
+    if (top->N > k::TAIL_MAX_N || top->N < 3) return false;
+
+    k::TailArgs a;
+    memset(&a, 0, sizeof a);
+    a.N[0] = top->N;
+    int depth = 0, max_depth = 0, at = x.at, n_nodes = 0;
+    size_t tok = x.tok;
+    int node_level[k::TAIL_MAX_NODES];
+    for (;;) {
+        if (tok >= p->tokens.size()) return false;
+        const int node = (int)p->tokens[tok++];
+        if (node == 1 && depth == 0) {  // leaves the tail: not ours
+            --tok;
+            break;
+        }
+        if (n_nodes >= k::TAIL_MAX_NODES) return false;
+        k::TailNode nd;
+        memset(&nd, 0, sizeof nd);
+        nd.type = node;
+        nd.err_slot = -1;
+        if (node == -1) {
+            if (at + 1 >= (int)p->sizes.size() || depth + 1 >= k::TAIL_MAX_LEVELS) return false;
+            nd.steps = p->con_step;
+            node_level[n_nodes] = depth;
+            ++depth;
+            a.N[depth] = p->sizes[(size_t)++at];
+            if (a.N[depth] < 3) return false;
+            if (depth > max_depth) max_depth = depth;
+        } else if (node == 0) {
+            if (tok + 1 >= p->tokens.size()) return false;
+            nd.tol = p->tokens[tok++];
+            if ((int)p->tokens[tok++] != 1) return false;
+            node_level[n_nodes] = depth;
+        } else if (node == 1) {
+            nd.steps = p->con_step;
+            --depth;
+            --at;
+            node_level[n_nodes] = depth;  // the level that is smoothed
+        } else {
+            return false;  // 2 / end of file / anything else inside the slice
+        }
+        a.nodes[n_nodes++] = nd;
+    }
+    if (n_nodes == 0 || at != x.at) return false;
+    a.n_nodes = n_nodes;
+    a.n_levels = max_depth + 1;
+    if (!k::tail_fits(a)) return false;
+    for (int l = 0; l < a.n_levels; ++l) {
+        const double dx = p->L / (double)(a.N[l] - 1);
+        a.dx2[l] = dx * dx;
+        a.inv[l] = 1.0 / a.dx2[l];
+        if (l + 1 < a.n_levels) {
+            const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
+            const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
+            if (!rt.lo || !pt.owner_row) return false;
+            a.r_lo[l] = rt.lo;
+            a.r_w[l] = rt.w;
+            a.p_orow[l] = pt.owner_row;
+            a.p_ocol[l] = pt.owner_col;
+            a.p_rhi[l] = pt.row_hi;
+            a.p_rlo[l] = pt.row_lo;
+            a.p_chi[l] = pt.col_hi;
+            a.p_clo[l] = pt.col_lo;
+            a.c_dx[l] = pt.c_dx;
+        }
+    }
+    // records + report, in the order the per-node interpreter would emit them
+    const char *down = "             *\n             |\n Restriction |\n             |\n             *\n";
+    const char *up = "             *\n             |\nProlongation |\n             |\n             *\n";
+    for (int i = 0; i < n_nodes; ++i) {
+        k::TailNode &nd = a.nodes[i];
+        const int N = a.N[node_level[i]];
+        if (nd.type == -1) {
+            nd.err_slot = add_record(p, -1, N, nd.steps);
+            report_smoothing(p, nd.err_slot);
+            report_text(p, down);
+        } else if (nd.type == 0) {
+            add_record(p, 0, N, 0);
+            if (p->flags & MG_CYCLE_REPORT) {
+                Text t;
+                t.printf("          ~Exact Solver~\n");
+                t.printf("Current Grid Size N = %d\n", N);
+                t.printf("   Use Exact Solver = GaussSeidel Even / Odd\n");
+                t.printf("       Target Error = %.3e\n", nd.tol);
+                report_text(p, t.s.c_str());
+            }
+        } else {
+            nd.err_slot = add_record(p, 1, N, nd.steps);
+            report_text(p, up);
+            report_smoothing(p, nd.err_slot);
+        }
+    }
+    a.F_top = top->F;
+    a.U_top = top->U;
+    a.err_dev = p->err_dev;
+    a.gs_state = x.c.gs_state;
+    {
+        ProfScope ps("coarse_tail", top->N, 0.0);
+        k::tail_launch(x.c.stream, a);
+    }
+    x.tok = tok;
+    return true;
+}
+
 // one pass over the node program == the reference's while loop :158-426
 void run_nodes(Exec &x)
 {
@@ -308,6 +424,9 @@ void run_nodes(Exec &x)
                     std::swap(lv->U, tmp);
                     p->pool.put(tmp);
                 }
+                report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
+                try_tail(x);  // levels N <= 64: the rest of this descent and its way back up in one launch
+                continue;
             } else {
                 rec = add_record(p, -1, lv->N, step);
                 smooth_level(x, lv, step, !keep, true, rec);

@@ -210,6 +210,34 @@ void analytic_error_rows(hipStream_t s, int N, double L, const double *U, const 
                          double min_y, double *out_raw);
 void fill_uniform(hipStream_t s, double *dst, size_t n, uint64_t seed);
 void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2]*/);
+// coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
+constexpr int TAIL_MAX_LEVELS = 6;
+constexpr int TAIL_MAX_NODES = 48;
+constexpr int TAIL_MAX_N = 64;
+struct TailNode {
+    int type;      // -1, 0, 1
+    int steps;     // smoothing steps (-1 / 1)
+    int err_slot;  // index into err_dev, or -1
+    int pad;
+    double tol;    // exact-solver target (0)
+};
+struct TailArgs {
+    int n_levels, n_nodes;
+    int N[TAIL_MAX_LEVELS];
+    double dx2[TAIL_MAX_LEVELS], inv[TAIL_MAX_LEVELS];
+    const int *r_lo[TAIL_MAX_LEVELS];      // restriction level l -> l+1
+    const double *r_w[TAIL_MAX_LEVELS];
+    const int *p_orow[TAIL_MAX_LEVELS], *p_ocol[TAIL_MAX_LEVELS];  // prolongation level l+1 -> l
+    const double *p_rhi[TAIL_MAX_LEVELS], *p_rlo[TAIL_MAX_LEVELS], *p_chi[TAIL_MAX_LEVELS], *p_clo[TAIL_MAX_LEVELS];
+    double c_dx[TAIL_MAX_LEVELS];
+    const double *F_top;
+    double *U_top;
+    double *err_dev;
+    int *gs_state;
+    TailNode nodes[TAIL_MAX_NODES];
+};
+bool tail_fits(const TailArgs &a);
+void tail_launch(hipStream_t s, const TailArgs &a);
 // red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]
 void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol,
                   int *state);
