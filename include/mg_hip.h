@@ -186,6 +186,10 @@ typedef struct mg_cycle_plan mg_cycle_plan;
 mg_cycle_plan *mg_cycle_load(const char *path, int flags);
 /* one run of the reference's timed window from the state right after getSource */
 int            mg_cycle_execute(mg_cycle_plan *plan, mg_cycle_result *out);
+/* the same window without host synchronisation: enqueue any number back to back, then collect
+ * (waits, reports the last one).  mg_cycle_execute == sync + enqueue + sync + collect. */
+int            mg_cycle_enqueue(mg_cycle_plan *plan);
+int            mg_cycle_collect(mg_cycle_plan *plan, mg_cycle_result *out);
 void           mg_cycle_destroy(mg_cycle_plan *plan);
 /* the whole reference program: load, execute, print report, write Sol_HIP_<file> CSV */
 int            mg_cycle_main(int argc, char **argv);

@@ -66,6 +66,7 @@ ABI = {
     "mg_prolongation_table": (None, [_i, _i, _i, _vp, _vp, _vp]),
     "mg_fill_uniform": (None, [_vp, _sz, _u64]), "mg_checksum": (None, [_vp, _sz, C.POINTER(_u64)]),
     "mg_cycle_load": (_vp, [C.c_char_p, _i]), "mg_cycle_execute": (_i, [_vp, C.POINTER(CycleResult)]),
+    "mg_cycle_enqueue": (_i, [_vp]), "mg_cycle_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_cycle_destroy": (None, [_vp]), "mg_cycle_main": (_i, [_i, C.POINTER(C.c_char_p)]),
     "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
     "mg_comm_unique_id_bytes": (_i, []), "mg_comm_get_unique_id": (_i, [_vp]),
@@ -377,9 +378,18 @@ class CyclePlan:
         if not self._plan:
             raise MGError(f"cannot load cycle file {path}")
 
-    def execute(self, fetch_U=False):
+    def enqueue(self):
+        """One window on the engine's stream, no host synchronisation (see collect)."""
+        status = _lib.mg_cycle_enqueue(self._plan)
+        _check()
+        return status
+
+    def collect(self, fetch_U=False):
+        return self.execute(fetch_U=fetch_U, _collect_only=True)
+
+    def execute(self, fetch_U=False, _collect_only=False):
         res = CycleResult()
-        status = _lib.mg_cycle_execute(self._plan, C.byref(res))
+        status = (_lib.mg_cycle_collect if _collect_only else _lib.mg_cycle_execute)(self._plan, C.byref(res))
         _check()
         out = dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
                    records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)

@@ -142,6 +142,7 @@ struct mg_cycle_plan {
     bool graph_ready = false, graph_failed = false;
     int warm_runs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_status = 0;
 };
 
 namespace {
@@ -587,23 +588,22 @@ mg_cycle_plan *mg_cycle_load(const char *path, int flags)
     return p;
 }
 
-int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
+// enqueue one run of the window on the engine's stream; no host synchronisation (fixed-step
+// cycle files).  Several windows may be enqueued back to back; mg_cycle_collect() then waits and
+// reports the LAST one.
+int mg_cycle_enqueue(mg_cycle_plan *p)
 {
-    if (!require_ready("mg_cycle_execute") || !p) return 1;
+    if (!require_ready("mg_cycle_enqueue") || !p) return 1;
     Context &c = ctx();
     hipStream_t s = c.stream;
-    memset(out, 0, sizeof *out);
-
     const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !uses_trigger(p) &&
                             !p->graph_failed;
     int status = 0;
-    mg_sync();
-    const auto t0 = std::chrono::steady_clock::now();  // :156
     (void)hipEventRecord(p->ev0, s);
 
     if (want_graph && p->graph_ready) {
         // the node program is static: replay it.  records/report keep their structure,
-        // only the error values are refreshed below.
+        // only the error values are refreshed at collect time.
         if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
     } else {
         reset_levels(p);
@@ -628,7 +628,7 @@ int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
                 if (g) (void)hipGraphDestroy(g);
                 p->graph_failed = true;
                 if (status == 8) status = 0;
-                // fall back to an eager pass so this execute still produces the result
+                // fall back to an eager pass so this window still produces the result
                 reset_levels(p);
                 Exec y{p, c};
                 run_nodes(y);
@@ -641,16 +641,23 @@ int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
         p->final_U = last->U;
         p->final_N = last->N;
     }
-
     (void)hipEventRecord(p->ev1, s);
+    p->last_status = status;
+    return status;
+}
+
+// wait for the enqueued windows and report the last one
+int mg_cycle_collect(mg_cycle_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_cycle_collect") || !p) return 1;
+    Context &c = ctx();
+    memset(out, 0, sizeof *out);
     mg_sync();
-    const auto t1 = std::chrono::steady_clock::now();  // :429
     float dev_ms = 0.f;
-    (void)hipEventElapsedTime(&dev_ms, p->ev0, p->ev1);
+    if (hipEventElapsedTime(&dev_ms, p->ev0, p->ev1) != hipSuccess) (void)hipGetLastError();
 
     // smoothing errors: one download for the whole window
-    std::vector<double> errs(p->records.size(), 0.0);
-    if (!errs.empty()) {
+    if (!p->records.empty()) {
         std::vector<double> all(p->records.size());
         mg_download(all.data(), p->err_dev, all.size());
         for (size_t i = 0; i < p->records.size(); ++i)
@@ -678,16 +685,30 @@ int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
         p->report = t.s;
     }
 
-    out->status = status ? status : (c.last_error ? 10 : 0);
+    out->status = p->last_status ? p->last_status : (c.last_error ? 10 : 0);
     out->N = p->final_N;
     out->U_dev = p->final_U;
     out->mg_error = mg_error;
-    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->time_ms = 0.0;
     out->device_ms = dev_ms;
     out->n_records = (int)p->records.size();
     out->records = p->records.data();
     out->report = p->report.c_str();
     return out->status;
+}
+
+// one synchronous run of the reference's timed window (:156 ... :429)
+int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_cycle_execute") || !p) return 1;
+    mg_sync();
+    const auto t0 = std::chrono::steady_clock::now();  // :156
+    mg_cycle_enqueue(p);
+    mg_sync();
+    const auto t1 = std::chrono::steady_clock::now();  // :429
+    const int status = mg_cycle_collect(p, out);
+    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return status;
 }
 
 void mg_cycle_destroy(mg_cycle_plan *p)
