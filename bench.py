@@ -41,6 +41,26 @@ def vcycle_algorithmic_bytes(sizes, nu1, nu2):
     return total
 
 
+def measured_traffic(kernel_family):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json, produced by scripts/profile.sh on the same command)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path)).get("kernels", {})
+    import re
+    m = re.match(r"jacobi_stream<(\d)(.*)>", kernel_family)
+    if not m:
+        return None
+    steps, rest = m.group(1), m.group(2)
+    mode = "2" if "prolong" in rest else ("1" if "zero" in rest else "0")
+    restrict = "true" if "restrict" in rest else "false"
+    for name, v in data.items():
+        if name.startswith(f"k_jacobi_stream<{steps}, 2, {mode}, {restrict}"):
+            return v["total_bytes"]
+    return None
+
+
 def cpu_baseline(cycle_path, lups, threads=None):
     """The reference's own operators (oracle/_ref/libmgref.so, built from /root/reference by
     oracle/Makefile) -- or, when that build is absent, the oracle's restatement -- timed on
@@ -142,7 +162,8 @@ def main():
     if kernels:
         k0 = kernels[0]
         roof = {"bound": "hbm", "kernel": k0["kernel"], "achieved": k0["algo_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(k0["algo_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(k0["algo_GBs"] / HBM_PEAK_GBS, 4),
+                "traffic": measured_traffic(k0["kernel"]) if N == 8192 else None,
                 "avg_ms": k0["avg_ms"], "launches": k0["launches"]}
 
     out = {

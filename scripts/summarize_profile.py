@@ -82,3 +82,32 @@ if fetch or write:
         avg = sum(d) / len(d) if d else 0.0
         gbs = (rd + wr) / (avg * 1e-6) / 1e9 if avg else 0.0
         print(f"| {k[0]} | {k[1]} | {len(d)} | {avg:.1f} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} | {gbs:.0f} |")
+
+
+# ---- per-kernel HBM bytes of the LARGEST launches (the finest level), for bench.py's roofline.traffic
+def top_cluster(sub, cname):
+    f = find(sub, "*counter_collection.csv")
+    acc = defaultdict(list)
+    if not f:
+        return {}
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") == cname:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    out = {}
+    for k, v in acc.items():
+        m = max(v)
+        top = [x for x in v if x > 0.5 * m]
+        out[k] = (sum(top) / len(top), len(top))
+    return out
+
+
+rd, wr = top_cluster("fetch", "FETCH_SIZE"), top_cluster("write", "WRITE_SIZE")
+traffic = {}
+for k in set(rd) | set(wr):
+    r = 2.0 * 1024 * rd.get(k, (0, 0))[0]   # gfx950: FETCH_SIZE counts half the bytes of a wide read
+    w = 1024 * wr.get(k, (0, 0))[0]
+    if r + w > 1e6:
+        traffic[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w, "launches": max(rd.get(k, (0, 0))[1], wr.get(k, (0, 0))[1])}
+with open(os.path.join(out_dir, "traffic.json"), "w") as f:
+    json.dump({"tag": tag, "note": "HBM bytes per launch of the finest-level launches; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB->B; separate --pmc passes",
+               "kernels": traffic}, f, indent=1)
