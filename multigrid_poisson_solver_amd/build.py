@@ -39,6 +39,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-result"]
+    common += os.environ.get("MG_EXTRA_CXXFLAGS", "").split()
     if force or _stale(LIB, deps):
         objs = []
         for s in srcs:

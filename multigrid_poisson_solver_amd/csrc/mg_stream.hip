@@ -155,14 +155,18 @@ __device__ __forceinline__ Row<COLS> load_row(const double *__restrict__ base)
     return r;
 }
 
+// nt: the array is far larger than the caches and is next read by a later kernel: a
+// non-temporal store keeps it from displacing the halo rows and coarse rows the neighbouring
+// tiles re-read (wave-uniform flag, set for N >= 2048)
 template <int COLS>
-__device__ __forceinline__ void store_row(double *__restrict__ base, const Row<COLS> &r)
+__device__ __forceinline__ void store_row(double *__restrict__ base, const Row<COLS> &r, bool nt)
 {
     if constexpr (COLS == 2) {
         double2_t t;
         t.x = r.v[0];
         t.y = r.v[1];
-        *reinterpret_cast<double2_t *>(base) = t;
+        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<double2_t *>(base));
+        else *reinterpret_cast<double2_t *>(base) = t;
     } else {
         *base = r.v[0];
     }
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const bool wave_has_rim_col = (own_x0 - H) <= 0 || (own_x0 - H + W - 1) >= N - 1;
 
     const double dx2 = p.dx2, inv = p.inv;
+    const bool nt_stores = N >= 2048;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
 
     // ---- fused prolongation input: per-lane column tables, coarse row cache ----------
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // nw is level S of row yin-S: the smoothed U
             {
                 const int y = yin - S;
-                if (y >= y0 && y < y1 && lane_owns) store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw);
+                if (y >= y0 && y < y1 && lane_owns) store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw, nt_stores);
             }
 
             // residual stage, row yin-S-1 (src/MG_solver_CPU.cpp:560 and the error sums :611)
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     // (row+col) even interior points only, :610/:617
                     if (mine && interior && (((y & 1) == 0) == col_even[j])) acc += fabs(r);
                 }
-                if (mine && p.D) store_row<COLS>(p.D + (size_t)(y - p.row_base) * N + xl, d);
+                if (mine && p.D) store_row<COLS>(p.D + (size_t)(y - p.row_base) * N + xl, d, nt_stores);
 
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
@@ -563,7 +568,9 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     const int resident = ctx().n_cu * blocks_per_cu;
     int chunks = resident / groups;
-    const int max_chunks = (own + 7) / 8;  // small grids: parallelism over halo economy
+    // small grids are latency bound on the length of a wave's march: shorter chunks, more waves
+    const int min_rows = N <= 1024 ? 4 : 8;
+    const int max_chunks = (own + min_rows - 1) / min_rows;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     const int rows = (own + chunks - 1) / chunks;

@@ -91,6 +91,56 @@ def test_generated_wcycle_full_depth_vs_oracle(mg, oracle, tmp_path):
     plan.close()
 
 
+def test_wcycle_2048_full_depth_vs_oracle(mg, oracle, tmp_path):
+    """BASELINE.json config 3 shape (W-cycle, recursion down to N = 8, 2^k coarse solves) at the
+    largest size the oracle still finishes in seconds; exercises the coarse-tail kernel with
+    a long node slice (36 nodes per visit of level 64)."""
+    path = str(tmp_path / "W2048.txt")
+    assert mg.write_wcycle_file(path, 2048, 8, 3, 1e-7) == 9
+    want = oracle.run_cycle_file(path, want_report=False)
+    for graph in (False, True):
+        plan = mg.CyclePlan(path, fused=True, graph=graph, report=False)
+        for _ in range(3 if graph else 1):
+            got = plan.execute(fetch_U=True)
+        assert got["status"] == 0
+        assert_bits(got["U"], want["U"], "W-cycle 2048 final U", zero_sign=True)
+        assert len(got["records"]) == len(want["records"])
+        for g, w in zip(got["records"], want["records"]):
+            assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+        plan.close()
+
+
+def test_back_to_back_windows(mg, oracle, tmp_path):
+    """mg_cycle_enqueue x K + mg_cycle_collect == K independent runs (each starts from U = 0)."""
+    path = str(tmp_path / "V512.txt")
+    mg.write_vcycle_file(path, 512, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path)
+    for graph in (False, True):
+        plan = mg.CyclePlan(path, fused=True, graph=graph)
+        plan.execute()
+        if graph:
+            plan.execute()
+        for _ in range(5):
+            plan.enqueue()
+        got = plan.collect(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        plan.close()
+
+
+def test_coarse_tail_matches_node_by_node(mg, tmp_path):
+    """MG_NO_TAIL=1 (read once per process) cannot be toggled here, so compare the fused driver
+    (tail kernel for N <= 64) with the unfused one (operator by operator) on a deep hierarchy."""
+    path = str(tmp_path / "V256_4.txt")
+    mg.write_vcycle_file(path, 256, 4, 2, 1e-8)  # levels 256 ... 4: the tail holds 64, 32, 16, 8, 4
+    a = mg.CyclePlan(path, fused=True)
+    b = mg.CyclePlan(path, fused=False)
+    ra, rb = a.execute(fetch_U=True), b.execute(fetch_U=True)
+    assert ra["status"] == 0 and rb["status"] == 0
+    assert_bits(ra["U"], rb["U"], "fused+tail vs unfused", zero_sign=True)
+    assert reports_match(ra["report"], rb["report"])
+    a.close(); b.close()
+
+
 def test_manual_grammar_con_step0_con_N0_and_minus_one(mg, oracle, tmp_path):
     """README.md:103-128: con_step=0 / con_N=0 (manual steps and sizes, non-nested sizes)
     and con_N=2 (N-1 per level)."""
