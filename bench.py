@@ -122,7 +122,8 @@ def main():
         visits = [1] * len(sizes)
     else:
         mg.write_wcycle_file(cyc, N, args.n_min, nu, 1e-7)
-        visits = [1] + [2 ** (l - 1) for l in range(1, len(sizes))]
+        # level l >= 1 is smoothed by 2^l '-1' nodes and 2^l '1' nodes (shipped src/Wcycle.txt recursion)
+        visits = [1] + [2 ** l for l in range(1, len(sizes))]
     # lattice updates of one step: (nu1+nu2) * sum over smoothed levels of n_l (x visits for W)
     lups = sum(2 * nu * v * s * s for s, v in zip(sizes[:-1], visits[:-1]))
     algo_bytes = vcycle_algorithmic_bytes(sizes, nu, nu) if args.cycle == "V" else None
