@@ -186,6 +186,31 @@ def main():
                                  "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     plan.close()
 
+    # north_star's own yardstick, measured beside the cycle: ONE fine-level Jacobi sweep per
+    # launch (doSmoothing with step = 1, 24 algorithmic bytes per point), both smoothers
+    try:
+        Ua, Ub, Ff = mg.DeviceGrid.uniform(N, 3), mg.DeviceGrid(N), mg.DeviceGrid.uniform(N, 7)
+        single = {}
+        for sm in ("stream", "simple"):
+            mg.set_smoother(sm)
+            for _ in range(3):
+                mg.smooth_pp(N, 1.0, Ua, Ub, Ff, 1)
+            mg.sync()
+            mg.profile_begin(min_N=N)
+            for _ in range(10):
+                mg.smooth_pp(N, 1.0, Ua, Ub, Ff, 1)
+            e = mg.profile_end()[0]
+            avg = e["total_ms"] / e["launches"]
+            gbs = 24.0 * N * N / (avg * 1e-3) / 1e9
+            single[sm] = {"kernel": e["name"], "avg_ms": round(avg, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        out["single_sweep_roofline"] = single
+        mg.set_smoother(args.smoother)
+        for g in (Ua, Ub, Ff):
+            g.free()
+    except mg.MGError as exc:  # never let the side measurement take the bench line down
+        out["single_sweep_roofline"] = {"error": str(exc)}
+
     if not args.no_cpu:
         cpu_n = args.cpu_n or N
         cpu_cyc = cyc

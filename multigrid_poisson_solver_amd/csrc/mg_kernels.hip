@@ -80,6 +80,36 @@ __global__ __launch_bounds__(TB) void k_jacobi_simple(int N, double dx2, const d
     }
 }
 
+// the same sweep for even N with 16 B per lane: a thread owns two adjacent points, reads the
+// rows above/below as aligned pairs and its two outer neighbours as single doubles (L1 hits of
+// the neighbouring lanes' pairs); one row per block, a massive grid of short blocks -- the
+// shape that streams closest to the HBM ceiling on MI355X (scripts/ubench/stream_ceiling.hip)
+typedef double double2_k __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(TB) void k_jacobi_pair(int N, double dx2, const double *__restrict__ in,
+                                                    const double *__restrict__ F, double *__restrict__ out)
+{
+    const int c = 2 * (blockIdx.x * TB + threadIdx.x);
+    const int r = blockIdx.y;
+    if (c >= N) return;
+    const size_t p = (size_t)r * N + c;
+    const double2_k ctr = *reinterpret_cast<const double2_k *>(in + p);
+    double2_k o = ctr;
+    if (r > 0 && r < N - 1) {
+        const double2_k up = *reinterpret_cast<const double2_k *>(in + p + N);
+        const double2_k dn = *reinterpret_cast<const double2_k *>(in + p - N);
+        const double2_k f = *reinterpret_cast<const double2_k *>(F + p);
+        if (c > 0) {  // point c: west neighbour is the previous lane's second value
+            const double w = in[p - 1];
+            o.x = ctr.x + 0.25 * (up.x + dn.x + ctr.y + w - 4 * ctr.x - dx2 * f.x);
+        }
+        if (c + 1 < N - 1) {  // point c+1: east neighbour is the next lane's first value
+            const double e = in[p + 2];
+            o.y = ctr.y + 0.25 * (up.y + dn.y + e + ctr.x - 4 * ctr.y - dx2 * f.y);
+        }
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<double2_k *>(out + p));
+}
+
 // ---------------------------------------------------------------- residual
 // src/MG_solver_CPU.cpp:554-564 (and the driver's sign flip :277-280 when sign < 0)
 __global__ __launch_bounds__(TB) void k_residual(int N, double inv, const double *__restrict__ U,
@@ -531,6 +561,10 @@ void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count)
 void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out)
 {
     const dim3 g = grid_rows(N, ROWS_PB);
+    if (in && N % 2 == 0 && N >= 512) {
+        hipLaunchKernelGGL(k_jacobi_pair, dim3((N / 2 + TB - 1) / TB, N), dim3(TB), 0, s, N, dx2, in, F, out);
+        return;
+    }
     if (in) hipLaunchKernelGGL(k_jacobi_simple<false>, g, dim3(TB), 0, s, N, dx2, in, F, out);
     else hipLaunchKernelGGL(k_jacobi_simple<true>, g, dim3(TB), 0, s, N, dx2, in, F, out);
 }

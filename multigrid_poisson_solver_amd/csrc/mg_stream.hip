@@ -74,6 +74,7 @@ struct StreamParams {
     int row_base, rows_local, own_y0, own_y1;
     int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
     int raw_norm;                   // error output is the raw sum over the owned rows
+    int nt_min_n;                   // grids at least this large store U/D non-temporally
     int fc_base, fc_rows;           // RESTRICT: window of Fc (global row of its first local row, rows)
     // IN_PROLONG: coarse grid and the host-built tables of doProlongation
     const double *coarse;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const bool wave_has_rim_col = (own_x0 - H) <= 0 || (own_x0 - H + W - 1) >= N - 1;
 
     const double dx2 = p.dx2, inv = p.inv;
-    const bool nt_stores = N >= 2048;
+    const bool nt_stores = N >= p.nt_min_n;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
 
     // ---- fused prolongation input: per-lane column tables, coarse row cache ----------
@@ -573,7 +574,9 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int max_chunks = (own + min_rows - 1) / min_rows;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
-    const int rows = (own + chunks - 1) / chunks;
+    int rows = (own + chunks - 1) / chunks;
+    static const int rows_cap = [] { const char *e = getenv("MG_MAX_ROWS"); return e ? atoi(e) : 0; }();
+    if (rows_cap > 0 && rows > rows_cap) rows = rows_cap;  // tuning knob: more, shorter tiles
     chunks = (own + rows - 1) / rows;
     p.rows_per_chunk = rows;
     p.groups = groups;
@@ -653,6 +656,8 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
     p.own_y0 = fine_w ? fine_w->own_lo : 0;
     p.own_y1 = fine_w ? fine_w->own_hi : N;
     p.raw_norm = fine_w ? 1 : 0;
+    static const int nt_min = [] { const char *e = getenv("MG_NT_MIN_N"); return e ? atoi(e) : 2048; }();
+    p.nt_min_n = nt_min;
     if (coarse) {
         p.coarse_base = coarse_w ? coarse_w->base : 0;
         p.coarse_rows = coarse_w ? coarse_w->rows : Nc;
