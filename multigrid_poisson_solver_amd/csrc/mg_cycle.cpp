@@ -408,7 +408,8 @@ void run_nodes(Exec &x)
                 mg_getResidual(lv->N, p->L, lv->U, lv->F, lv->D);  // :239
                 mg_negate(lv->N, lv->D);                           // :277-280
                 report_smoothing(p, rec);
-                cycle.Push_back(next_N);                                        // :283
+                cycle.Push_back(next_N);  // :283
+                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
                 mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);  // :287
             } else if (fused) {
                 // smoothing (:259), residual (:268), sign flip (:277-280) and restriction (:287)
@@ -416,6 +417,7 @@ void run_nodes(Exec &x)
                 rec = add_record(p, -1, lv->N, step);
                 report_smoothing(p, rec);
                 cycle.Push_back(next_N);  // :283
+                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
                 double *Fc = cycle.last()->F;
                 if (!keep) {
                     mg_smooth_restrict(lv->N, p->L, nullptr, lv->U, lv->F, step, error_slot(p, rec), next_N, Fc);
@@ -432,7 +434,8 @@ void run_nodes(Exec &x)
                 rec = add_record(p, -1, lv->N, step);
                 smooth_level(x, lv, step, !keep, true, rec);
                 report_smoothing(p, rec);
-                cycle.Push_back(next_N);                                        // :283
+                cycle.Push_back(next_N);  // :283
+                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
                 mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);  // :287
             }
             report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");

@@ -284,6 +284,12 @@ void run(mg_slab_plan *p)
             nxt.collapsed = p->level_collapsed[(size_t)hier];
             if (!nxt.collapsed) nxt.part = p->parts[(size_t)hier];
             alloc_level(p, nxt);
+            {
+                bool ok = true;
+                for (const Local &l : nxt.loc)
+                    if ((nxt.collapsed ? is_root_local(p) : true) && (!l.U || !l.F || !l.D)) ok = false;
+                if (!ok) { p->status = 14; break; }  // out of device memory
+            }
             if ((int)p->records.size() >= (int)p->max_rec) { p->status = 11; break; }
 
             if (cur.collapsed) {

@@ -181,3 +181,24 @@ def test_command_line_program(mg, tmp_path):
     assert "OpenMP threads = 4" in out.stdout and "Cycle structure file name = test.txt" in out.stdout
     assert "    Error = 0.000666" in out.stdout and "Output file name = Sol_HIP_test.txt" in out.stdout
     assert (tmp_path / "Sol_HIP_test.txt").read_text() == open(os.path.join(GOLDEN, "Sol_CPU_test.txt.csv")).read()
+
+
+@pytest.mark.parametrize("name", ["test.txt", "Vcycle.txt", "Wcycle.txt", "VcycleTrigger.txt"])
+def test_reference_main_drives_the_engine(mg, golden_reports, tmp_path, name):
+    """Drop-in proof: oracle/_ref/MG_HIP_dropin is the REFERENCE's main() and linked list
+    (src/MG_solver_CPU.cpp:36-462, src/linkedlist.cpp), compiled where the sources lie with the
+    edits of INTEGRATION.md (oracle/dropin_build.sh) against libmgpoisson.so through
+    include/mg_dropin.hpp.  It must print what the reference program printed and write the
+    same CSV."""
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "MG_HIP_dropin")
+    exe = os.path.abspath(exe)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/MG_HIP_dropin not built (needs /root/reference at build time)")
+    shutil.copy(os.path.join(GOLDEN, "cycles", name), tmp_path)
+    out = subprocess.run([exe, "4", name], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    body = "".join(l for l in out.stdout.splitlines(keepends=True)
+                   if not l.startswith(("OpenMP threads", "Cycle structure file", "Time Used", "Output file name")))
+    assert reports_match(body, golden_reports[name])
+    if name == "test.txt":
+        assert (tmp_path / "Sol_CPU_test.txt").read_text() == open(os.path.join(GOLDEN, "Sol_CPU_test.txt.csv")).read()
