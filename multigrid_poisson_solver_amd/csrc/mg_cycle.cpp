@@ -145,6 +145,85 @@ struct mg_cycle_plan {
     int last_status = 0;
 };
 
+namespace mg {
+// Shared by the single-GPU and the row-slab driver: starting at tokens[*tok], collect the slice
+// of the node stream that stays on the level of size top_N (<= TAIL_MAX_N) and below, up to but
+// not including the `1` that leaves it, into a TailArgs (levels, spacings, transfer tables; the
+// caller fills F_top/U_top/err_dev/gs_state and the error slots).  node_level[i] = tail level
+// node i works on.  Returns false, consuming nothing, when the slice has another shape.
+bool scan_tail(const std::vector<double> &tokens, size_t *tok_io, const std::vector<int> &sizes, int at0, int con_step,
+               int top_N, double L, k::TailArgs *out, int *node_level)
+{
+    static const bool disabled = getenv("MG_NO_TAIL") != nullptr;
+    if (disabled || con_step < 1 || top_N > k::TAIL_MAX_N || top_N < 3) return false;
+    k::TailArgs &a = *out;
+    memset(&a, 0, sizeof a);
+    a.N[0] = top_N;
+    int depth = 0, max_depth = 0, at = at0, n_nodes = 0;
+    size_t tok = *tok_io;
+    for (;;) {
+        if (tok >= tokens.size()) return false;
+        const int node = (int)tokens[tok++];
+        if (node == 1 && depth == 0) {  // leaves the tail: not ours
+            --tok;
+            break;
+        }
+        if (n_nodes >= k::TAIL_MAX_NODES) return false;
+        k::TailNode nd;
+        memset(&nd, 0, sizeof nd);
+        nd.type = node;
+        nd.err_slot = -1;
+        if (node == -1) {
+            if (at + 1 >= (int)sizes.size() || depth + 1 >= k::TAIL_MAX_LEVELS) return false;
+            nd.steps = con_step;
+            node_level[n_nodes] = depth;
+            ++depth;
+            a.N[depth] = sizes[(size_t)++at];
+            if (a.N[depth] < 3) return false;
+            if (depth > max_depth) max_depth = depth;
+        } else if (node == 0) {
+            if (tok + 1 >= tokens.size()) return false;
+            nd.tol = tokens[tok++];
+            if ((int)tokens[tok++] != 1) return false;
+            node_level[n_nodes] = depth;
+        } else if (node == 1) {
+            nd.steps = con_step;
+            --depth;
+            --at;
+            node_level[n_nodes] = depth;  // the level that is smoothed
+        } else {
+            return false;  // 2 / end of file / anything else inside the slice
+        }
+        a.nodes[n_nodes++] = nd;
+    }
+    if (n_nodes == 0 || at != at0) return false;
+    a.n_nodes = n_nodes;
+    a.n_levels = max_depth + 1;
+    if (!k::tail_fits(a)) return false;
+    for (int l = 0; l < a.n_levels; ++l) {
+        const double dx = L / (double)(a.N[l] - 1);
+        a.dx2[l] = dx * dx;
+        a.inv[l] = 1.0 / a.dx2[l];
+        if (l + 1 < a.n_levels) {
+            const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
+            const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
+            if (!rt.lo || !pt.owner_row) return false;
+            a.r_lo[l] = rt.lo;
+            a.r_w[l] = rt.w;
+            a.p_orow[l] = pt.owner_row;
+            a.p_ocol[l] = pt.owner_col;
+            a.p_rhi[l] = pt.row_hi;
+            a.p_rlo[l] = pt.row_lo;
+            a.p_chi[l] = pt.col_hi;
+            a.p_clo[l] = pt.col_lo;
+            a.c_dx[l] = pt.c_dx;
+        }
+    }
+    *tok_io = tok;
+    return true;
+}
+}  // namespace mg
+
 namespace {
 
 const double TRIGGER = 0.01;  // src/MG_solver_CPU.cpp:99
@@ -262,75 +341,14 @@ bool try_tail(Exec &x)
 {
     mg_cycle_plan *p = x.p;
     LevelList &cycle = *p->levels;
-    static const bool disabled = getenv("MG_NO_TAIL") != nullptr;
-    if (disabled || p->con_N != 1 || p->con_step < 1) return false;
+    if (p->con_N != 1) return false;
     LevelNode *top = cycle.last();
-    if (top->N > k::TAIL_MAX_N || top->N < 3) return false;
 
     k::TailArgs a;
-    memset(&a, 0, sizeof a);
-    a.N[0] = top->N;
-    int depth = 0, max_depth = 0, at = x.at, n_nodes = 0;
-    size_t tok = x.tok;
     int node_level[k::TAIL_MAX_NODES];
-    for (;;) {
-        if (tok >= p->tokens.size()) return false;
-        const int node = (int)p->tokens[tok++];
-        if (node == 1 && depth == 0) {  // leaves the tail: not ours
-            --tok;
-            break;
-        }
-        if (n_nodes >= k::TAIL_MAX_NODES) return false;
-        k::TailNode nd;
-        memset(&nd, 0, sizeof nd);
-        nd.type = node;
-        nd.err_slot = -1;
-        if (node == -1) {
-            if (at + 1 >= (int)p->sizes.size() || depth + 1 >= k::TAIL_MAX_LEVELS) return false;
-            nd.steps = p->con_step;
-            node_level[n_nodes] = depth;
-            ++depth;
-            a.N[depth] = p->sizes[(size_t)++at];
-            if (a.N[depth] < 3) return false;
-            if (depth > max_depth) max_depth = depth;
-        } else if (node == 0) {
-            if (tok + 1 >= p->tokens.size()) return false;
-            nd.tol = p->tokens[tok++];
-            if ((int)p->tokens[tok++] != 1) return false;
-            node_level[n_nodes] = depth;
-        } else if (node == 1) {
-            nd.steps = p->con_step;
-            --depth;
-            --at;
-            node_level[n_nodes] = depth;  // the level that is smoothed
-        } else {
-            return false;  // 2 / end of file / anything else inside the slice
-        }
-        a.nodes[n_nodes++] = nd;
-    }
-    if (n_nodes == 0 || at != x.at) return false;
-    a.n_nodes = n_nodes;
-    a.n_levels = max_depth + 1;
-    if (!k::tail_fits(a)) return false;
-    for (int l = 0; l < a.n_levels; ++l) {
-        const double dx = p->L / (double)(a.N[l] - 1);
-        a.dx2[l] = dx * dx;
-        a.inv[l] = 1.0 / a.dx2[l];
-        if (l + 1 < a.n_levels) {
-            const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
-            const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
-            if (!rt.lo || !pt.owner_row) return false;
-            a.r_lo[l] = rt.lo;
-            a.r_w[l] = rt.w;
-            a.p_orow[l] = pt.owner_row;
-            a.p_ocol[l] = pt.owner_col;
-            a.p_rhi[l] = pt.row_hi;
-            a.p_rlo[l] = pt.row_lo;
-            a.p_chi[l] = pt.col_hi;
-            a.p_clo[l] = pt.col_lo;
-            a.c_dx[l] = pt.c_dx;
-        }
-    }
+    size_t tok = x.tok;
+    if (!scan_tail(p->tokens, &tok, p->sizes, x.at, p->con_step, top->N, p->L, &a, node_level)) return false;
+    const int n_nodes = a.n_nodes;
     // records + report, in the order the per-node interpreter would emit them
     const char *down = "             *\n             |\n Restriction |\n             |\n             *\n";
     const char *up = "             *\n             |\nProlongation |\n             |\n             *\n";

@@ -244,4 +244,8 @@ void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const 
 int  gs_single_workgroup_max_n();
 }  // namespace k
 
+// collect the coarse-tail slice of a cycle file's node stream (mg_cycle.cpp)
+bool scan_tail(const std::vector<double> &tokens, size_t *tok_io, const std::vector<int> &sizes, int at0, int con_step,
+               int top_N, double L, k::TailArgs *out, int *node_level);
+
 }  // namespace mg

@@ -297,6 +297,29 @@ void run(mg_slab_plan *p)
                 if (is_root_local(p))
                     mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[0].U, cur.loc[0].F, step, raw_slot(p, (size_t)rec, 0), M,
                                        nxt.loc[0].F);
+                // levels N <= 64: the rest of this descent and its way back up in one launch on the
+                // root (every rank walks the same slice so tokens and records stay in step)
+                k::TailArgs ta;
+                int node_level[k::TAIL_MAX_NODES];
+                size_t tk = tok;
+                if (scan_tail(p->tokens, &tk, p->sizes, at, step, M, p->L, &ta, node_level) &&
+                    p->records.size() + (size_t)ta.n_nodes < p->max_rec) {
+                    for (int i = 0; i < ta.n_nodes; ++i) {
+                        k::TailNode &nd = ta.nodes[i];
+                        const int r2 = add_record(p, nd.type, ta.N[node_level[i]], nd.type == 0 ? 0 : nd.steps, 1);
+                        // error slots index raw_dev directly: the root's slot of record r2
+                        if (nd.type != 0) nd.err_slot = (int)((size_t)r2 * p->local.size());
+                    }
+                    if (is_root_local(p)) {
+                        ta.F_top = nxt.loc[0].F;
+                        ta.U_top = nxt.loc[0].U;
+                        ta.err_dev = p->raw_dev;
+                        ta.gs_state = c.gs_state;
+                        ProfScope ps("coarse_tail", M, 0.0);
+                        k::tail_launch(c.stream, ta);
+                    }
+                    tok = tk;
+                }
             } else {
                 const int rec = add_record(p, -1, cur.N, step, 0);
                 const Partition cpart = nxt.collapsed ? induced_partition(cur.part, cur.N, M) : nxt.part;
