@@ -618,6 +618,8 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
     // Large grids fill the chip with waves: fewer registers (PF = 2) win.  Small grids are latency
     // bound on one wave per SIMD: a deeper FIFO (PF = 4) covers the memory latency instead.
     static const int forced = [] { const char *e = getenv("MG_PF"); return e ? atoi(e) : 0; }();
+    // (PF = 8 was tried for tiny grids and is slower: there a lone wave is bound by its own
+    // instruction stream, ~0.6 us per row, not by memory latency)
     const int pf = forced ? forced : (p.N <= 2048 ? 4 : 2);
     if (pf == 2) launch_variant<S, 2>(s, p, err_out);
     else launch_variant<S, 4>(s, p, err_out);
