@@ -206,6 +206,15 @@ def main():
                           "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         out["single_sweep_roofline"] = single
         mg.set_smoother(args.smoother)
+        # the box's own device-to-device copy rate: the practical ceiling SURVEY.md 8d asks for
+        mg.lib().mg_copy(Ub.ptr, Ua.ptr, Ua.size)
+        mg.sync()
+        tc = time.perf_counter()
+        for _ in range(10):
+            mg.lib().mg_copy(Ub.ptr, Ua.ptr, Ua.size)
+        mg.sync()
+        tc = (time.perf_counter() - tc) / 10
+        out["device_copy_GBs"] = round(16.0 * N * N / tc / 1e9, 1)
         for g in (Ua, Ub, Ff):
             g.free()
     except mg.MGError as exc:  # never let the side measurement take the bench line down
