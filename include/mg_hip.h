@@ -223,6 +223,9 @@ typedef struct mg_slab_plan mg_slab_plan;
 mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N);
 /* one run of the reference's timed window; U_dev is NULL (use mg_slab_gather_U) */
 int  mg_slab_execute(mg_slab_plan *plan, mg_cycle_result *out);
+/* like mg_cycle_enqueue / mg_cycle_collect */
+int  mg_slab_enqueue(mg_slab_plan *plan);
+int  mg_slab_collect(mg_slab_plan *plan, mg_cycle_result *out);
 /* owned rows of this process's slabs of the finest U into a full N x N host array */
 int  mg_slab_gather_U(mg_slab_plan *plan, double *host_full);
 /* mg_error (src/MG_solver_CPU.cpp:434-445) is evaluated after each window unless turned off */

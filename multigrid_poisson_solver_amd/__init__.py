@@ -74,6 +74,7 @@ ABI = {
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
+    "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
     "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
 }
@@ -464,9 +465,17 @@ class SlabPlan:
         if not self._plan:
             raise MGError(f"cannot load cycle file {path} in row-slab mode")
 
-    def execute(self):
+    def enqueue(self):
+        status = _lib.mg_slab_enqueue(self._plan)
+        _check()
+        return status
+
+    def collect(self):
+        return self.execute(_collect_only=True)
+
+    def execute(self, _collect_only=False):
         res = CycleResult()
-        status = _lib.mg_slab_execute(self._plan, C.byref(res))
+        status = (_lib.mg_slab_collect if _collect_only else _lib.mg_slab_execute)(self._plan, C.byref(res))
         _check()
         return dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
                     records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)

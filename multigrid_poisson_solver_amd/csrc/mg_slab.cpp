@@ -7,9 +7,12 @@
 // blocked, ONE exchange of ghost rows feeds a whole fused node (S sweeps + residual +
 // restriction, or prolongation + S sweeps): per level and V-cycle there is one exchange of
 // the next level's F on the way down and one of (coarse U, fine U) on the way up.
-// Levels at or below collapse_N live on rank 0 only: their F is
-// gathered after the last distributed restriction, rank 0 runs that part of the cycle file
-// with the single-GPU operators, and the coarse correction is broadcast back.
+// Levels at or below collapse_N are collapsed: after the last
+// distributed restriction every rank hands its rows of that level's F to the others, and
+// EVERY rank -- rank 0 included -- runs that part of the cycle file on the whole coarse grid
+// with the single-GPU operators.  Replicating the collapsed levels instead of parking them on
+// rank 0 costs nothing (the other ranks would idle) and removes the broadcast of the coarse
+// correction from the critical path; all ranks hold bit-identical copies.
 //
 // Ranks may all live in THIS process ("virtual ranks": exchanges are device-to-device
 // copies) -- that is how the decomposition is tested bit-for-bit on a one-GPU box -- or one
@@ -83,9 +86,9 @@ struct Local {  // one local rank's arrays of one level
 
 struct Level {
     int N = 0;
-    bool collapsed = false;   // whole grid on the root rank only
+    bool collapsed = false;   // whole grid replicated on every rank
     Partition part;           // distributed levels
-    std::vector<Local> loc;   // per local rank (collapsed: one entry, used on the root only)
+    std::vector<Local> loc;   // per local rank (collapsed: full N x N arrays, distributed: windows)
 };
 
 }  // namespace
@@ -107,7 +110,6 @@ struct mg_slab_plan {
     std::vector<Level> levels;
     std::vector<Partition> parts;       // per hierarchy index (sizes[i]), distributed ones only
     std::vector<bool> level_collapsed;  // per hierarchy index
-    std::vector<double *> stage;        // per local rank: a full coarse array at the collapse boundary
     std::vector<mg_node_record> records;
     std::vector<int> rec_final;         // 1: the root's slot already holds the finished value
     double *raw_dev = nullptr;          // [max_rec][n_local] raw sums (+1 row for the analytic error)
@@ -120,7 +122,6 @@ struct mg_slab_plan {
 
 namespace {
 
-bool is_root_local(const mg_slab_plan *p) { return p->local[0] == 0; }
 RowWindow window_of(const Partition &part, int r)
 {
     RowWindow w;
@@ -135,17 +136,16 @@ double *row_ptr(double *a, const RowWindow &w, int N, int y) { return a + (size_
 
 void alloc_level(mg_slab_plan *p, Level &lv)
 {
+    lv.loc.resize(p->local.size());
     if (lv.collapsed) {
-        lv.loc.resize(1);
-        if (is_root_local(p)) {
-            const size_t bytes = (size_t)lv.N * lv.N * sizeof(double);
-            lv.loc[0].U = (double *)p->pool.get(bytes);
-            lv.loc[0].F = (double *)p->pool.get(bytes);
-            lv.loc[0].D = (double *)p->pool.get(bytes);
+        const size_t bytes = (size_t)lv.N * lv.N * sizeof(double);
+        for (Local &l : lv.loc) {
+            l.U = (double *)p->pool.get(bytes);
+            l.F = (double *)p->pool.get(bytes);
+            l.D = (double *)p->pool.get(bytes);
         }
         return;
     }
-    lv.loc.resize(p->local.size());
     for (size_t i = 0; i < p->local.size(); ++i) {
         const RowWindow w = window_of(lv.part, p->local[i]);
         const size_t bytes = (size_t)w.rows * lv.N * sizeof(double);
@@ -165,80 +165,79 @@ void free_level(mg_slab_plan *p, Level &lv)
     lv.loc.clear();
 }
 
-// ghost rows of one array of a distributed level: every rank sends its top GHOST owned rows up
-// and its bottom GHOST owned rows down, and receives the neighbours' into its halo
+// ghost rows of arrays of distributed levels: every rank sends its top GHOST owned rows up and
+// its bottom GHOST owned rows down, and receives the neighbours' into its halo.  All arrays of
+// one call travel in ONE RCCL group (one launch, both neighbours, both directions).
 enum Which { ARR_U, ARR_F };
-void exchange_ghosts(mg_slab_plan *p, Level &lv, Which which)
+struct GhostItem {
+    Level *lv;
+    Which which;
+};
+void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items)
 {
     Context &c = ctx();
-    const int N = lv.N, R = p->nranks;
-    const size_t cnt = (size_t)GHOST * N;
-    auto arr = [&](size_t i) { return which == ARR_U ? lv.loc[i].U : lv.loc[i].F; };
-    if (!p->real) {
-        for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
-            const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
-            double *A = arr((size_t)r), *B = arr((size_t)r + 1);
-            // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
-            (void)hipMemcpyAsync(row_ptr(B, b, N, b.own_lo - GHOST), row_ptr(A, a, N, a.own_hi - GHOST),
-                                 cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-            (void)hipMemcpyAsync(row_ptr(A, a, N, a.own_hi), row_ptr(B, b, N, b.own_lo), cnt * sizeof(double),
-                                 hipMemcpyDeviceToDevice, c.stream);
+    const int R = p->nranks;
+    if (items.empty() || R == 1) return;
+    if (p->real) comm_group_begin();
+    for (const GhostItem &it : items) {
+        Level &lv = *it.lv;
+        const int N = lv.N;
+        const size_t cnt = (size_t)GHOST * N;
+        auto arr = [&](size_t i) { return it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F; };
+        if (!p->real) {
+            for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
+                const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
+                double *A = arr((size_t)r), *B = arr((size_t)r + 1);
+                // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
+                (void)hipMemcpyAsync(row_ptr(B, b, N, b.own_lo - GHOST), row_ptr(A, a, N, a.own_hi - GHOST),
+                                     cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+                (void)hipMemcpyAsync(row_ptr(A, a, N, a.own_hi), row_ptr(B, b, N, b.own_lo), cnt * sizeof(double),
+                                     hipMemcpyDeviceToDevice, c.stream);
+            }
+            continue;
         }
-        return;
+        const int r = p->local[0];
+        const RowWindow w = window_of(lv.part, r);
+        double *A = arr(0);
+        if (r + 1 < R) {
+            comm_send(row_ptr(A, w, N, w.own_hi - GHOST), cnt, r + 1);
+            comm_recv(row_ptr(A, w, N, w.own_hi), cnt, r + 1);
+        }
+        if (r > 0) {
+            comm_send(row_ptr(A, w, N, w.own_lo), cnt, r - 1);
+            comm_recv(row_ptr(A, w, N, w.own_lo - GHOST), cnt, r - 1);
+        }
     }
-    const int r = p->local[0];
-    const RowWindow w = window_of(lv.part, r);
-    double *A = arr(0);
-    comm_group_begin();
-    if (r + 1 < R) {
-        comm_send(row_ptr(A, w, N, w.own_hi - GHOST), cnt, r + 1);
-        comm_recv(row_ptr(A, w, N, w.own_hi), cnt, r + 1);
-    }
-    if (r > 0) {
-        comm_send(row_ptr(A, w, N, w.own_lo), cnt, r - 1);
-        comm_recv(row_ptr(A, w, N, w.own_lo - GHOST), cnt, r - 1);
-    }
-    comm_group_end();
+    if (p->real) comm_group_end();
 }
 
-// rows of the full coarse array each rank produced (stage buffers) -> the root's F
-void gather_to_root(mg_slab_plan *p, const Partition &cpart, int M, double *root_F)
+// collapse boundary: every rank wrote its rows [cpart.lo, cpart.hi) of the coarse F into its own
+// full M x M array; afterwards every rank holds all rows (an all-gather with per-rank row
+// counts, issued as one group of point-to-point transfers)
+void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart)
 {
     Context &c = ctx();
+    const int M = coarse.N, R = p->nranks;
+    if (R == 1) return;
+    auto off = [&](int r) { return (size_t)cpart.lo[(size_t)r] * M; };
+    auto cnt = [&](int r) { return (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M; };
     if (!p->real) {
-        for (size_t i = 0; i < p->local.size(); ++i) {
-            const int r = p->local[i];
-            const size_t off = (size_t)cpart.lo[(size_t)r] * M;
-            const size_t cnt = (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M;
-            (void)hipMemcpyAsync(root_F + off, p->stage[i] + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-        }
+        for (int src = 0; src < R; ++src)
+            for (int dst = 0; dst < R; ++dst)
+                if (src != dst)
+                    (void)hipMemcpyAsync(coarse.loc[(size_t)dst].F + off(src), coarse.loc[(size_t)src].F + off(src),
+                                         cnt(src) * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
         return;
     }
     const int me = p->local[0];
+    double *F = coarse.loc[0].F;
     comm_group_begin();
-    if (me == 0) {
-        const size_t cnt0 = (size_t)(cpart.hi[0] - cpart.lo[0]) * M;
-        (void)hipMemcpyAsync(root_F, p->stage[0], cnt0 * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-        for (int r = 1; r < p->nranks; ++r)
-            comm_recv(root_F + (size_t)cpart.lo[(size_t)r] * M, (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M, r);
-    } else {
-        comm_send(p->stage[0] + (size_t)cpart.lo[(size_t)me] * M, (size_t)(cpart.hi[(size_t)me] - cpart.lo[(size_t)me]) * M, 0);
+    for (int r = 0; r < R; ++r) {
+        if (r == me) continue;
+        comm_send(F + off(me), cnt(me), r);
+        comm_recv(F + off(r), cnt(r), r);
     }
     comm_group_end();
-}
-
-// the root's full coarse U -> every local rank's stage buffer
-void broadcast_from_root(mg_slab_plan *p, int M, const double *root_U)
-{
-    Context &c = ctx();
-    const size_t cnt = (size_t)M * M;
-    if (!p->real) {
-        for (size_t i = 0; i < p->local.size(); ++i)
-            (void)hipMemcpyAsync(p->stage[i], root_U, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-        return;
-    }
-    if (p->local[0] == 0) (void)hipMemcpyAsync(p->stage[0], root_U, cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-    comm_bcast(p->stage[0], cnt, 0);
 }
 
 double *raw_slot(mg_slab_plan *p, size_t rec, size_t local_i) { return p->raw_dev + rec * p->local.size() + local_i; }
@@ -287,36 +286,37 @@ void run(mg_slab_plan *p)
             {
                 bool ok = true;
                 for (const Local &l : nxt.loc)
-                    if ((nxt.collapsed ? is_root_local(p) : true) && (!l.U || !l.F || !l.D)) ok = false;
+                    if (!l.U || !l.F || !l.D) ok = false;
                 if (!ok) { p->status = 14; break; }  // out of device memory
             }
             if ((int)p->records.size() >= (int)p->max_rec) { p->status = 11; break; }
 
             if (cur.collapsed) {
                 const int rec = add_record(p, -1, cur.N, step, 1);
-                if (is_root_local(p))
-                    mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[0].U, cur.loc[0].F, step, raw_slot(p, (size_t)rec, 0), M,
-                                       nxt.loc[0].F);
-                // levels N <= 64: the rest of this descent and its way back up in one launch on the
-                // root (every rank walks the same slice so tokens and records stay in step)
+                for (size_t i = 0; i < p->local.size(); ++i)
+                    mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), M,
+                                       nxt.loc[i].F);
+                // levels N <= 64: the rest of this descent and its way back up in one launch
+                // (every rank walks the same slice, so tokens and records stay in step)
                 k::TailArgs ta;
                 int node_level[k::TAIL_MAX_NODES];
                 size_t tk = tok;
                 if (scan_tail(p->tokens, &tk, p->sizes, at, step, M, p->L, &ta, node_level) &&
                     p->records.size() + (size_t)ta.n_nodes < p->max_rec) {
-                    for (int i = 0; i < ta.n_nodes; ++i) {
-                        k::TailNode &nd = ta.nodes[i];
-                        const int r2 = add_record(p, nd.type, ta.N[node_level[i]], nd.type == 0 ? 0 : nd.steps, 1);
-                        // error slots index raw_dev directly: the root's slot of record r2
-                        if (nd.type != 0) nd.err_slot = (int)((size_t)r2 * p->local.size());
-                    }
-                    if (is_root_local(p)) {
-                        ta.F_top = nxt.loc[0].F;
-                        ta.U_top = nxt.loc[0].U;
-                        ta.err_dev = p->raw_dev;
-                        ta.gs_state = c.gs_state;
+                    int rec_of[k::TAIL_MAX_NODES];
+                    for (int i = 0; i < ta.n_nodes; ++i)
+                        rec_of[i] = add_record(p, ta.nodes[i].type, ta.N[node_level[i]],
+                                               ta.nodes[i].type == 0 ? 0 : ta.nodes[i].steps, 1);
+                    for (size_t li = 0; li < p->local.size(); ++li) {
+                        k::TailArgs mine = ta;
+                        for (int i = 0; i < mine.n_nodes; ++i)  // error slots index raw_dev directly
+                            if (mine.nodes[i].type != 0) mine.nodes[i].err_slot = (int)((size_t)rec_of[i] * p->local.size() + li);
+                        mine.F_top = nxt.loc[li].F;
+                        mine.U_top = nxt.loc[li].U;
+                        mine.err_dev = p->raw_dev;
+                        mine.gs_state = c.gs_state;
                         ProfScope ps("coarse_tail", M, 0.0);
-                        k::tail_launch(c.stream, ta);
+                        k::tail_launch(c.stream, mine);
                     }
                     tok = tk;
                 }
@@ -328,34 +328,33 @@ void run(mg_slab_plan *p)
                     SlabFusion sf;
                     sf.fine_w = window_of(cur.part, r);
                     sf.M = M;
-                    if (nxt.collapsed) {  // every rank writes its rows of a full coarse array
-                        sf.Fc = p->stage[i];
-                        sf.fc_w = RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]};
-                    } else {
-                        sf.Fc = nxt.loc[i].F;
-                        sf.fc_w = window_of(nxt.part, r);
-                    }
+                    sf.Fc = nxt.loc[i].F;
+                    // a collapsed next level is a full array on every rank: this rank writes its rows
+                    sf.fc_w = nxt.collapsed ? RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]} : window_of(nxt.part, r);
                     // U starts from zero on every descent (:252-257; a restart inside one file is
-                    // not supported in slab mode), so no U ghost exchange is needed here
+                    // not supported in slab mode), so no U ghost exchange is needed before the launch
                     slab_smooth(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
                 }
-                if (nxt.collapsed) {
-                    if (is_root_local(p) || p->real) gather_to_root(p, cpart, M, is_root_local(p) ? nxt.loc[0].F : nullptr);
-                } else {
-                    p->levels.push_back(nxt);
-                    exchange_ghosts(p, p->levels.back(), ARR_F);
-                    continue;
-                }
+                p->levels.push_back(nxt);
+                Level &fine_lv = p->levels[p->levels.size() - 2], &next_lv = p->levels.back();
+                // ONE group: the next level's F halo (needed by its own descent) and this level's U
+                // halo (needed when the cycle comes back up through this level)
+                std::vector<GhostItem> items;
+                items.push_back(GhostItem{&fine_lv, ARR_U});
+                if (!next_lv.collapsed) items.push_back(GhostItem{&next_lv, ARR_F});
+                exchange_ghosts(p, items);
+                if (next_lv.collapsed) share_rows(p, next_lv, cpart);
+                continue;
             }
             p->levels.push_back(nxt);
         } else if (node == 0) {  // :305-324
             double tol, opt;
             if (!next(&tol) || !next(&opt)) { p->status = 3; break; }
             Level &cur = p->levels.back();
-            if (!cur.collapsed) { p->status = 12; break; }  // the exact solver runs on the root only
+            if (!cur.collapsed) { p->status = 12; break; }  // the exact solver runs on collapsed levels only
             if ((int)opt != 1) { p->status = 5; break; }
             add_record(p, 0, cur.N, 0, 1);
-            if (is_root_local(p)) mg_doExactSolver(cur.N, p->L, cur.loc[0].U, cur.loc[0].F, tol, 1);
+            for (size_t i = 0; i < p->local.size(); ++i) mg_doExactSolver(cur.N, p->L, cur.loc[i].U, cur.loc[i].F, tol, 1);
         } else if (node == 1) {  // prolong + add + smooth, :329-424
             --at;
             if (p->levels.size() < 2) { p->status = 6; break; }
@@ -365,28 +364,23 @@ void run(mg_slab_plan *p)
             if ((int)p->records.size() >= (int)p->max_rec) { p->status = 11; break; }
             if (fine.collapsed) {
                 const int rec = add_record(p, 1, fine.N, step, 1);
-                if (is_root_local(p)) {
-                    mg_prolong_smooth(coarse.N, coarse.loc[0].U, fine.N, p->L, fine.loc[0].U, fine.loc[0].D, fine.loc[0].F,
-                                      step, raw_slot(p, (size_t)rec, 0));
-                    std::swap(fine.loc[0].U, fine.loc[0].D);
+                for (size_t i = 0; i < p->local.size(); ++i) {
+                    mg_prolong_smooth(coarse.N, coarse.loc[i].U, fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F,
+                                      step, raw_slot(p, (size_t)rec, i));
+                    std::swap(fine.loc[i].U, fine.loc[i].D);
                 }
             } else {
                 const int rec = add_record(p, 1, fine.N, step, 0);
-                if (coarse.collapsed) broadcast_from_root(p, coarse.N, is_root_local(p) ? coarse.loc[0].U : nullptr);
-                else exchange_ghosts(p, coarse, ARR_U);
-                exchange_ghosts(p, fine, ARR_U);
+                // the fine level's U halo was exchanged right after its descent; a distributed coarse
+                // level's U was just produced and needs its halo now, a collapsed one is whole
+                if (!coarse.collapsed) exchange_ghosts(p, {GhostItem{&coarse, ARR_U}});
                 for (size_t i = 0; i < p->local.size(); ++i) {
                     const int r = p->local[i];
                     SlabFusion sf;
                     sf.fine_w = window_of(fine.part, r);
                     sf.Nc = coarse.N;
-                    if (coarse.collapsed) {
-                        sf.coarse = p->stage[i];
-                        sf.coarse_w = RowWindow{0, coarse.N, 0, coarse.N};
-                    } else {
-                        sf.coarse = coarse.loc[i].U;
-                        sf.coarse_w = window_of(coarse.part, r);
-                    }
+                    sf.coarse = coarse.loc[i].U;
+                    sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse.part, r);
                     slab_smooth(fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
                     std::swap(fine.loc[i].U, fine.loc[i].D);
                 }
@@ -402,6 +396,8 @@ void run(mg_slab_plan *p)
 }  // namespace
 
 extern "C" {
+
+int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 
 // host-only: the row ranges each rank owns on every level of the hierarchy a cycle file
 // generates (N_max, halving down to N_min), and which levels are collapsed onto rank 0.
@@ -494,12 +490,6 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
         delete p;
         return nullptr;
     }
-    // a full coarse array per local rank for the collapse boundary
-    size_t stage_n = 0;
-    for (size_t l = 1; l < nl; ++l)
-        if (p->level_collapsed[l] && !p->level_collapsed[l - 1]) stage_n = (size_t)p->sizes[l] * p->sizes[l];
-    for (size_t i = 0; i < p->local.size(); ++i) p->stage.push_back(stage_n ? (double *)p->pool.get(stage_n * sizeof(double)) : nullptr);
-
     size_t smoothing_nodes = 0;
     for (double t : p->tokens)
         if (t == -1.0 || t == 1.0 || t == 0.0) ++smoothing_nodes;
@@ -524,11 +514,11 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
     return p;
 }
 
-int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
+// one window on the engine's stream, no host synchronisation (see mg_cycle_enqueue)
+int mg_slab_enqueue(mg_slab_plan *p)
 {
-    if (!require_ready("mg_slab_execute") || !p) return 1;
+    if (!require_ready("mg_slab_enqueue") || !p) return 1;
     Context &c = ctx();
-    memset(out, 0, sizeof *out);
     while (p->levels.size() > 1) {
         free_level(p, p->levels.back());
         p->levels.pop_back();
@@ -538,16 +528,35 @@ int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
     p->status = 0;
     c.active_pool = &p->pool;
     (void)hipMemsetAsync(p->raw_dev, 0, (p->max_rec + 1) * p->local.size() * sizeof(double), c.stream);
-    mg_sync();
-    const auto t0 = std::chrono::steady_clock::now();
     (void)hipEventRecord(p->ev0, c.stream);
     run(p);
     (void)hipEventRecord(p->ev1, c.stream);
+    c.active_pool = nullptr;
+    return p->status;
+}
+
+int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_slab_execute") || !p) return 1;
+    mg_sync();
+    const auto t0 = std::chrono::steady_clock::now();
+    mg_slab_enqueue(p);
     mg_sync();
     const auto t1 = std::chrono::steady_clock::now();
-    c.active_pool = nullptr;
+    const int status = mg_slab_collect(p, out);
+    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return status;
+}
+
+// wait for the enqueued windows and report the last one
+int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
+{
+    if (!require_ready("mg_slab_collect") || !p) return 1;
+    Context &c = ctx();
+    memset(out, 0, sizeof *out);
+    mg_sync();
     float dev_ms = 0.f;
-    (void)hipEventElapsedTime(&dev_ms, p->ev0, p->ev1);
+    if (hipEventElapsedTime(&dev_ms, p->ev0, p->ev1) != hipSuccess) (void)hipGetLastError();
 
     // outside the window: the analytic error (:434-445) and the smoothing errors, combined
     // over the slabs in rank order
@@ -586,7 +595,7 @@ int mg_slab_execute(mg_slab_plan *p, mg_cycle_result *out)
     out->N = top.N;
     out->U_dev = nullptr;
     out->mg_error = a / (double)(top.N * top.N);
-    out->time_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->time_ms = 0.0;
     out->device_ms = dev_ms;
     out->n_records = (int)nrec;
     out->records = p->records.data();
@@ -618,8 +627,6 @@ void mg_slab_destroy(mg_slab_plan *p)
     if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
     for (Level &lv : p->levels) free_level(p, lv);
     p->levels.clear();
-    for (double *s : p->stage)
-        if (s) p->pool.put(s);
     if (p->raw_dev) p->pool.put(p->raw_dev);
     if (p->all_dev) p->pool.put(p->all_dev);
     if (p->ev0) (void)hipEventDestroy(p->ev0);

@@ -87,6 +87,12 @@ def main():
             if rank == world - 1:
                 chi = M
         assert not np.isnan(Fc[clo:chi]).any(), f"rank {rank}: NaN in owned coarse F rows {M}"
+        # the engine exchanges this level's U halo right here, in the same group as the next
+        # level's F halo: it is needed when the cycle comes back up through this level
+        Ul = np.full((n, n), np.nan)
+        Ul[lo:hi] = U[l][lo:hi]
+        exchange(Ul, lo, hi, G, rank, world)
+        U[l] = Ul
         if l + 1 < first_collapsed:
             F[l + 1] = np.full((M, M), np.nan)
             F[l + 1][clo:chi] = Fc[clo:chi]
@@ -98,12 +104,13 @@ def main():
             for a, b, rows in parts:
                 full[a:b] = rows
             assert not np.isnan(full).any()
-            F[l + 1] = full  # only rank 0 uses it
+            F[l + 1] = full  # every rank holds the whole collapsed level
 
-    # ---- the collapsed part of the V-cycle on rank 0, whole grids, plain oracle operators
+    # ---- the collapsed part of the V-cycle, replicated on EVERY rank (whole grids, plain oracle
+    # operators): no broadcast of the coarse correction is needed afterwards
     lc = first_collapsed
     coarse_U = np.empty((sizes[lc], sizes[lc]))
-    if rank == 0:
+    if True:
         def vcycle(l, Fl):
             n = sizes[l]
             if l == len(sizes) - 1:
@@ -115,8 +122,6 @@ def main():
             Ul, _ = orc.doSmoothing(n, L, Ul, Fl, step)
             return Ul
         coarse_U[:] = vcycle(lc, F[lc])
-    t = torch.from_numpy(coarse_U)
-    dist.broadcast(t, 0)
     U[lc] = coarse_U
 
     # ---- up through the distributed levels
@@ -130,9 +135,7 @@ def main():
             exchange(Uc, clo, chi, G, rank, world)
         else:
             Uc = U[l + 1]
-        Uf = np.full((n, n), np.nan)
-        Uf[lo:hi] = U[l][lo:hi]
-        exchange(Uf, lo, hi, G, rank, world)
+        Uf = U[l]  # owned rows + the halo exchanged right after this level's descent
         Uf = orc.doGridAddition(n, Uf, orc.doProlongation(M, Uc, n, fill=np.nan))
         U[l], _ = orc.doSmoothing(n, L, Uf, F[l], step)
         assert not np.isnan(U[l][lo:hi]).any(), f"rank {rank}: NaN in owned rows after the way up, level {n}"
