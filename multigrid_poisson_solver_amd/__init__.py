@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmgpoisson.so")
+LIB_PATH = os.environ.get("MG_LIB") or os.path.join(_PKG, "lib", "libmgpoisson.so")  # MG_LIB: A/B builds
 EXE_PATH = os.path.join(_PKG, "bin", "MG_HIP")
 
 MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT, MG_CYCLE_ERROR = 1, 2, 4, 8
