@@ -257,6 +257,47 @@ def test_golden_odd_pairs_kats_and_gs(mg, golden_ops):
         assert_bits(U.to_host(), g[f"gs_N{N}_U"], f"golden GaussSeidel {N}")
 
 
+def test_reference_test_program_configurations(mg, oracle):
+    """The shapes the reference's own hand-run comparison programs use:
+    Test_doSmoothing_GPU.cu (N=16, rand U/F, 10 steps), Test_getResidual_GPU.cu (N=16),
+    Test_doExactSolver_GPU_Double.cu (N=16, tol 1e-3, option 1) and Test_doProlongation_GPU.cu,
+    which UPSAMPLES with doRestriction used as a generic zoom (N=4 -> M=8, :233)."""
+    N = 16
+    rng = np.random.default_rng(2020)
+    U0, F = rng.random((N, N)), rng.random((N, N))  # rand()/RAND_MAX: uniform [0,1]
+    U, Fd = mg.DeviceGrid.from_host(U0), mg.DeviceGrid.from_host(F)
+    err = mg.doSmoothing(N, 1.0, U, Fd, 10)
+    want, werr = oracle.doSmoothing(N, 1.0, U0, F, 10)
+    assert_bits(U.to_host(), want, "Test_doSmoothing shape")
+    assert err == pytest.approx(werr, rel=REL)
+    D = mg.DeviceGrid(N)
+    mg.getResidual(N, 1.0, mg.DeviceGrid.from_host(U0), Fd, D)
+    assert_bits(D.to_host(), oracle.getResidual(N, 1.0, U0, F), "Test_getResidual shape")
+    G = mg.DeviceGrid.from_host(U0)
+    mg.doExactSolver(N, 1.0, G, Fd, 1e-3, 1)
+    assert_bits(G.to_host(), oracle.doExactSolver(N, 1.0, F, 1e-3), "Test_doExactSolver shape")
+    ramp4 = np.add.outer(np.arange(4.0), np.arange(4.0))
+    out = mg.DeviceGrid.from_host(np.full((8, 8), np.nan))
+    mg.doRestriction(4, mg.DeviceGrid.from_host(ramp4), 8, out)   # "restriction" 4 -> 8: a zoom
+    zoom = oracle.doRestriction(4, ramp4, 8)
+    assert_bits(out.to_host(), zoom, "doRestriction as generic zoom 4->8")
+    ix = np.arange(8.0)
+    np.testing.assert_allclose(zoom[1:-1, 1:-1], (np.add.outer(ix, ix) * 3.0 / 7.0)[1:-1, 1:-1], rtol=1e-13)
+
+
+def test_engine_on_a_torch_stream_and_tensors():
+    """PyTorch is plumbing here (device memory, streams): the engine enqueues on a caller's
+    hipStream and works on memory it did not allocate.  Runs in a subprocess because torch has to
+    be imported before the engine library (one HIP runtime per process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "_torch_interop_worker.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "TORCH_INTEROP OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ synthetic data
 def test_synthetic_fill_and_checksum(mg):
     for N, seed in ((64, 11), (257, 22)):
