@@ -53,6 +53,25 @@ def test_virtual_slabs_wcycle_and_other_steps(mg, oracle, tmp_path, R):
     plan.close()
 
 
+@pytest.mark.parametrize("R", [2, 8])
+def test_virtual_slabs_on_the_weak_scaling_size_family(mg, oracle, tmp_path, R):
+    """bench.py --gpus 2/8 runs N = 11584 / 23168 = 2^k * 181: the hierarchy halves down to the odd
+    size 181 and on to 90, 45, 22, 11.  Same chain at 1/8 of the size: 1448 -> 724 distributed,
+    362 -> 181 -> 90 -> 45 -> 22 -> 11 collapsed (odd levels, non-nested transfers, coarse tail)."""
+    N = 1448
+    path = str(tmp_path / "V1448.txt")
+    assert mg.write_vcycle_file(path, N, 8, 3, 1e-7) == 8
+    want = oracle.run_cycle_file(path)
+    plan = mg.SlabPlan(path, R, -1, 400)
+    got = plan.execute()
+    check(got, plan.gather_U(N), want)
+    plan.close()
+    single = mg.CyclePlan(path, fused=True, report=False)
+    ref = single.execute(fetch_U=True)
+    assert_bits(ref["U"], want["U"], "single-GPU driver on the same file", zero_sign=True)
+    single.close()
+
+
 def test_virtual_slabs_match_single_gpu_driver_at_4096(mg, tmp_path):
     """8 slabs of a 4096^2 V-cycle against the single-GPU driver (itself pinned to the oracle)."""
     N = 4096
