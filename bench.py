@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=8192, help="finest grid size N (N x N points)")
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MG_BENCH_N", "8192")),
+                    help="finest grid size N (N x N points); under torchrun use env MG_BENCH_N (its parser eats --n)")
     ap.add_argument("--n-min", type=int, default=8)
     ap.add_argument("--nu", type=int, default=3, help="smoothing steps per node (V(nu,nu))")
     ap.add_argument("--cycle", choices=["V", "W"], default="V")
