@@ -44,6 +44,15 @@ def assert_bits(a, b, what="", zero_sign=False):
 
 
 @pytest.fixture(scope="session")
+def cycle_dir(tmp_path_factory):
+    """Directory holding the cycle-structure inputs of the tests (written from tests/_cycles.py)."""
+    import _cycles
+    d = tmp_path_factory.mktemp("cycles")
+    _cycles.write_all(d)
+    return str(d)
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import _oracle
     return _oracle.Oracle()

@@ -79,14 +79,14 @@ def per_op_vectors(ref):
 
 def end_to_end(orc, ref):
     """(3) end-to-end goldens: reference program output on the shipped cycle files."""
-    cyc_dir = os.path.join(HERE, "cycles")
-    os.makedirs(cyc_dir, exist_ok=True)
-    arrays, reports = {}, {}
+    import _cycles
+    cyc_dir = tempfile.mkdtemp(prefix="mgcycles_")
+    _cycles.write_all(cyc_dir)
+    # the token streams of tests/_cycles.py ARE the reference's shipped files
     for name in CYCLES:
-        shutil.copy(os.path.join(REF_SRC, name), os.path.join(cyc_dir, name))
-    # config 1 of BASELINE.json: N=128 plumbing case (header 128 8, 4 down / 4 up)
-    with open(os.path.join(cyc_dir, "Vcycle128.txt"), "w") as f:
-        f.write("1.0 0.0 0.0\n3 1\n128 8\n" + "-1\n" * 4 + "0\n0.0000001 1\n" + "1\n" * 4 + "2")
+        ref_tokens = [float(t) for t in open(os.path.join(REF_SRC, name)).read().split()]
+        assert ref_tokens == [float(t) for t in _cycles.text(name).split()], name
+    arrays, reports = {}, {}
     for name in CYCLES + ["Vcycle128.txt"]:
         d = tempfile.mkdtemp()
         shutil.copy(os.path.join(cyc_dir, name), d)

@@ -46,8 +46,8 @@ def check_against(got, want, zero_sign):
 
 @pytest.mark.parametrize("name", CYCLES)
 @pytest.mark.parametrize("mode", ["unfused", "fused", "graph"])
-def test_shipped_cycle_files_vs_oracle_and_golden(mg, oracle, golden_reports, golden_e2e, name, mode):
-    path = os.path.join(GOLDEN, "cycles", name)
+def test_shipped_cycle_files_vs_oracle_and_golden(mg, oracle, golden_reports, golden_e2e, cycle_dir, name, mode):
+    path = os.path.join(cycle_dir, name)
     plan = mg.CyclePlan(path, fused=(mode != "unfused"), graph=(mode == "graph"))
     want = oracle.run_cycle_file(path)
     runs = 3 if mode == "graph" else 1  # warm, capture, replay
@@ -171,11 +171,11 @@ def test_malformed_cycle_files(mg, oracle, tmp_path):
         mg.CyclePlan(str(tmp_path / "does_not_exist.txt"))
 
 
-def test_command_line_program(mg, tmp_path):
+def test_command_line_program(mg, cycle_dir, tmp_path):
     """MG_HIP keeps the reference's command line and output format
     (src/MG_solver_CPU.cpp:51-68, :448-459); the CSV of test.txt must equal the one the
     reference program wrote (fixture tests/golden/Sol_CPU_test.txt.csv)."""
-    shutil.copy(os.path.join(GOLDEN, "cycles", "test.txt"), tmp_path)
+    shutil.copy(os.path.join(cycle_dir, "test.txt"), tmp_path)
     out = subprocess.run([mg.EXE_PATH, "4", "test.txt"], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "OpenMP threads = 4" in out.stdout and "Cycle structure file name = test.txt" in out.stdout
@@ -184,7 +184,7 @@ def test_command_line_program(mg, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["test.txt", "Vcycle.txt", "Wcycle.txt", "VcycleTrigger.txt"])
-def test_reference_main_drives_the_engine(mg, golden_reports, tmp_path, name):
+def test_reference_main_drives_the_engine(mg, golden_reports, cycle_dir, tmp_path, name):
     """Drop-in proof: oracle/_ref/MG_HIP_dropin is the REFERENCE's main() and linked list
     (src/MG_solver_CPU.cpp:36-462, src/linkedlist.cpp), compiled where the sources lie with the
     edits of INTEGRATION.md (oracle/dropin_build.sh) against libmgpoisson.so through
@@ -194,7 +194,7 @@ def test_reference_main_drives_the_engine(mg, golden_reports, tmp_path, name):
     exe = os.path.abspath(exe)
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/MG_HIP_dropin not built (needs /root/reference at build time)")
-    shutil.copy(os.path.join(GOLDEN, "cycles", name), tmp_path)
+    shutil.copy(os.path.join(cycle_dir, name), tmp_path)
     out = subprocess.run([exe, "4", name], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     body = "".join(l for l in out.stdout.splitlines(keepends=True)

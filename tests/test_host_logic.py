@@ -129,10 +129,11 @@ def test_product_prolongation_table_reproduces_oracle_values(m, oracle):
 def test_cycle_file_generators(m, tmp_path):
     v = tmp_path / "v.txt"
     m.write_vcycle_file(str(v), 256, 8, 3, 1e-7)
-    shipped = open(os.path.join(GOLDEN, "cycles", "Vcycle.txt")).read().split()
+    import _cycles
+    shipped = _cycles.text("Vcycle.txt").split()
     assert [float(t) for t in v.read_text().split()] == [float(t) for t in shipped]
     w = tmp_path / "w.txt"
     m.write_wcycle_file(str(w), 256, 8, 3, 1e-8, depth=4)
-    shipped = open(os.path.join(GOLDEN, "cycles", "Wcycle.txt")).read().split()
+    shipped = _cycles.text("Wcycle.txt").split()
     assert [float(t) for t in w.read_text().split()] == [float(t) for t in shipped]
     assert m.write_vcycle_file(str(v), 8192, 8) == 11

@@ -78,8 +78,8 @@ def test_oracle_tables_vs_golden(oracle, golden_tables):
 
 
 @pytest.mark.parametrize("name", ["test.txt", "Vcycle.txt", "Wcycle.txt", "VcycleTrigger.txt", "Vcycle128.txt"])
-def test_oracle_driver_vs_golden(oracle, golden_reports, golden_e2e, name):
-    res = oracle.run_cycle_file(os.path.join(GOLDEN, "cycles", name))
+def test_oracle_driver_vs_golden(oracle, golden_reports, golden_e2e, cycle_dir, name):
+    res = oracle.run_cycle_file(os.path.join(cycle_dir, name))
     assert res["status"] == 0
     assert res["report"] == golden_reports[name]
     assert res["mg_error"] == pytest.approx(golden_reports[name + ":mg_error"], rel=1e-12)
@@ -147,12 +147,12 @@ def test_oracle_vs_reference_ops(oracle, reference, N):
         assert_bits(oracle.doExactSolver(N, 1.0, F, 1e-7), reference.doExactSolver(N, 1.0, F, 1e-7), "GaussSeidel")
 
 
-def test_oracle_driver_vs_reference_program(oracle, reference, tmp_path):
+def test_oracle_driver_vs_reference_program(oracle, reference, cycle_dir, tmp_path):
     """The reference PROGRAM (oracle/_ref/MG_CPU_ref) on the shipped cycle files: same
     printed report, same CSV, and the reference operators under the oracle driver give the
     same U bit for bit."""
     for name in ["test.txt", "Vcycle.txt", "VcycleTrigger.txt", "Wcycle.txt"]:
-        shutil.copy(os.path.join(GOLDEN, "cycles", name), tmp_path)
+        shutil.copy(os.path.join(cycle_dir, name), tmp_path)
         stdout = subprocess.run([_oracle.REF_EXE, "2", name], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
         body = "".join(l for l in stdout.splitlines(keepends=True)
                        if not l.startswith(("OpenMP threads", "Cycle structure file", "Time Used", "Output file name")))
