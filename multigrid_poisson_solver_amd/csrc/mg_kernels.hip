@@ -9,6 +9,7 @@
 // segment of a row.  The temporally blocked smoother lives in mg_stream.hip.
 #include <hip/hip_runtime.h>
 
+#include "mg_gs_wave.h"
 #include "mg_internal.h"
 
 namespace mg {
@@ -410,64 +411,15 @@ __global__ __launch_bounds__(1024) void k_gs_workgroup(int N, double h2, double 
 }
 
 // grids of at most 64 points (N <= 8, the coarsest level of every shipped cycle file): ONE
-// wave, one point per lane, U in a register; neighbours through ds_bpermute, the norm
-// through a DPP row scan + 4 readlanes -- no LDS traffic, no barriers.
-template <int SHIFT>
-__device__ __forceinline__ double row_shr_zero(double v)
-{
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x110 + SHIFT, 0xf, 0xf, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x110 + SHIFT, 0xf, 0xf, true);
-    return r.d;
-}
-__device__ __forceinline__ double read_lane(double v, int lane)
-{
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
-    r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
-    return r.d;
-}
-__device__ __forceinline__ double wave_total(double v)
-{
-    v += row_shr_zero<1>(v);
-    v += row_shr_zero<2>(v);
-    v += row_shr_zero<4>(v);
-    v += row_shr_zero<8>(v);   // lanes 15, 31, 47, 63 hold their row's total
-    return ((read_lane(v, 15) + read_lane(v, 31)) + read_lane(v, 47)) + read_lane(v, 63);
-}
-
+// wave, one point per lane, U in a register (mg_gs_wave.h) -- no LDS traffic, no barriers.
 __global__ __launch_bounds__(64) void k_gs_wave(int N, double h2, double inv, double *__restrict__ Ug,
                                                 const double *__restrict__ Fg, double tol, int *__restrict__ state)
 {
     const int lane = threadIdx.x;
     const int n = N * N;
-    const int r = lane / N, c = lane - r * N;
-    const bool inside = lane < n && !rim(r, c, N);
-    const int colour = (r + c) & 1;
     const double f = lane < n ? Fg[lane] : 0.0;
-    const double h2f = h2 * f;
-    const int l_w = lane > 0 ? lane - 1 : 0, l_e = lane < 63 ? lane + 1 : 63;
-    const int l_s = lane >= N ? lane - N : 0, l_n = lane + N < 64 ? lane + N : 63;
-    const double denom = (double)((N - 2) * (N - 2));
-    double u = 0.0;  // memset(U, 0)  :993
     int iterations = 0;
-    for (;;) {
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
-            const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
-            const double nu = 0.25 * (w + e + nn + ss - h2f);  // :1020 U[l]+U[r]+U[t]+U[b] - h^2 F
-            if (inside && colour == pass) u = nu;
-        }
-        ++iterations;
-        const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
-        const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
-        const double res = inside ? fabs(inv * (nn + ss + e + w - 4 * u) - f) : 0.0;  // :560
-        const double err = wave_total(res) / denom;  // :1059
-        if (!(err > tol) || iterations >= GS_MAX_ITER) break;
-    }
+    const double u = gsw::solve(N, h2, inv, f, tol, GS_MAX_ITER, &iterations);
     if (lane < n) Ug[lane] = u;
     if (lane == 0) {
         state[0] = 1;

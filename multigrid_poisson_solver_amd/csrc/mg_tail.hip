@@ -10,6 +10,7 @@
 // -ffp-contract=off), so the result is bit-identical to running the nodes one by one.
 #include <hip/hip_runtime.h>
 
+#include "mg_gs_wave.h"
 #include "mg_internal.h"
 
 namespace mg {
@@ -123,60 +124,16 @@ __device__ void gauss_seidel_block(int N, double h2, double inv, int src, int F,
     }
 }
 
-template <int SHIFT>
-__device__ __forceinline__ double row_shr_zero(double v)
-{
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x110 + SHIFT, 0xf, 0xf, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x110 + SHIFT, 0xf, 0xf, true);
-    return r.d;
-}
-__device__ __forceinline__ double read_lane(double v, int lane)
-{
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
-    r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
-    return r.d;
-}
-
 // the same solve for a grid of at most 64 points, by wave 0 alone with U in registers
-// (the algorithm of mg_kernels.hip:k_gs_wave); the other waves wait at the barrier
+// (mg_gs_wave.h); the other waves wait at the barrier
 __device__ void gauss_seidel_wave(int N, double h2, double inv, int src, int F, double tol, int *state)
 {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int n = N * N;
-        const int r = lane / N, c = lane - r * N;
-        const bool inside = lane < n && !rim(r, c, N);
-        const int colour = (r + c) & 1;
         const double f = lane < n ? FF(lane) : 0.0;
-        const double h2f = h2 * f;
-        const int l_w = lane > 0 ? lane - 1 : 0, l_e = lane < 63 ? lane + 1 : 63;
-        const int l_s = lane >= N ? lane - N : 0, l_n = lane + N < 64 ? lane + N : 63;
-        const double denom = (double)((N - 2) * (N - 2));
-        double u = 0.0;
         int iterations = 0;
-        for (;;) {
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
-                const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
-                const double nu = 0.25 * (w + e + nn + ss - h2f);
-                if (inside && colour == pass) u = nu;
-            }
-            ++iterations;
-            const double w = __shfl(u, l_w, 64), e = __shfl(u, l_e, 64);
-            const double nn = __shfl(u, l_n, 64), ss = __shfl(u, l_s, 64);
-            double v = inside ? fabs(inv * (nn + ss + e + w - 4 * u) - f) : 0.0;
-            v += row_shr_zero<1>(v);
-            v += row_shr_zero<2>(v);
-            v += row_shr_zero<4>(v);
-            v += row_shr_zero<8>(v);
-            const double err = (((read_lane(v, 15) + read_lane(v, 31)) + read_lane(v, 47)) + read_lane(v, 63)) / denom;
-            if (!(err > tol) || iterations >= 50000000) break;
-        }
+        const double u = gsw::solve(N, h2, inv, f, tol, 50000000, &iterations);
         if (lane < n) SRC(lane) = u;
         if (lane == 0) {
             state[0] = 1;
