@@ -111,6 +111,19 @@ void mg_smooth_restrict(int N, double L, const double *U_in, double *U_out, doub
 /* one "1" node of the driver (:353-416): U_out = smooth^step(U_in + doProlongation(Nc, U_c, N)) */
 void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double *U_in, double *U_out,
                        double *F, int step, double *error_dev);
+/* mixed-precision mode (README.md:269-270 of the reference: "single
+ * precision" GPU kernels): the two fused nodes with every array and every arithmetic operation
+ * in fp32 (norms in fp64).  Zero start only; 1..4 steps; even N; nested coarse size. */
+void   mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, float *F, int step,
+                              double *error_dev, int M, float *F_c);
+void   mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out,
+                             float *F, int step, double *error_dev);
+float *mg_alloc_f32(size_t n_floats);
+void   mg_free_f32(float *dev);
+void   mg_to_f32(float *dst_dev, const double *src_dev, size_t n);   /* round to nearest */
+void   mg_to_f64(double *dst_dev, const float *src_dev, size_t n);   /* exact */
+void   mg_upload_f32(float *dev, const float *host, size_t n);       /* synchronous */
+void   mg_download_f32(float *host, const float *dev, size_t n);     /* synchronous */
 /* U_f_out = U_f_in + doProlongation(N, U_c, M) in one pass (:354 + :368) */
 void mg_prolongAdd(int N, const double *U_c, int M, const double *U_f_in, double *U_f_out);
 /* doRestriction(N, sign*U_f, M, U_c) */
@@ -180,6 +193,8 @@ typedef struct mg_cycle_plan mg_cycle_plan;
 #define MG_CYCLE_GRAPH   2 /* capture the node program into a hipGraph and replay it */
 #define MG_CYCLE_REPORT  4 /* build the printed report text */
 #define MG_CYCLE_ERROR   8 /* evaluate mg_error (:434-445) after the window, as the program does */
+#define MG_CYCLE_MIXED  16 /* the whole cycle in fp32 (F rounded once at load, U widened at the end);
+                              fixed-step halving files whose coarse part fits the tail kernel */
 
 /* parse a cycle structure file (README.md:43-128); allocates the finest level and
  * evaluates getSource on it (:149-153, outside the timed window) */

@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MG_LIB") or os.path.join(_PKG, "lib", "libmgpoisson.so")  # MG_LIB: A/B builds
 EXE_PATH = os.path.join(_PKG, "bin", "MG_HIP")
 
-MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT, MG_CYCLE_ERROR = 1, 2, 4, 8
+MG_CYCLE_FUSED, MG_CYCLE_GRAPH, MG_CYCLE_REPORT, MG_CYCLE_ERROR, MG_CYCLE_MIXED = 1, 2, 4, 8, 16
 
 
 class MGError(RuntimeError):
@@ -60,6 +60,11 @@ ABI = {
     "mg_smooth_pp": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "mg_smooth_restrict": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "mg_prolong_smooth": (None, [_i, _vp, _i, _d, _vp, _vp, _vp, _i, _vp]),
+    "mg_smooth_restrict_f32": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "mg_prolong_smooth_f32": (None, [_i, _vp, _i, _d, _vp, _vp, _vp, _i, _vp]),
+    "mg_alloc_f32": (_vp, [_sz]), "mg_free_f32": (None, [_vp]), "mg_to_f32": (None, [_vp, _vp, _sz]),
+    "mg_to_f64": (None, [_vp, _vp, _sz]), "mg_upload_f32": (None, [_vp, _vp, _sz]),
+    "mg_download_f32": (None, [_vp, _vp, _sz]),
     "mg_prolongAdd": (None, [_i, _vp, _i, _vp, _vp]), "mg_restrict_signed": (None, [_i, _vp, _i, _vp, _i]),
     "mg_lastExactSolverIterations": (_i, []),
     "mg_restriction_table": (None, [_i, _i, _vp, _vp]),
@@ -221,6 +226,63 @@ class DeviceGrid:
             pass
 
 
+class DeviceGrid32:
+    """fp32 device array (mixed-precision mode)."""
+
+    def __init__(self, shape):
+        if isinstance(shape, int):
+            shape = (shape, shape)
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(np.prod(self.shape))
+        self.ptr = lib().mg_alloc_f32(self.size)
+        _check()
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        g = cls(a.shape)
+        _lib.mg_upload_f32(g.ptr, a.ctypes.data, a.size)
+        _check()
+        return g
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float32)
+        _lib.mg_download_f32(out.ctypes.data, self.ptr, self.size)
+        _check()
+        return out
+
+    def free(self):
+        if self.ptr and _initialised:
+            _lib.mg_free_f32(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def smooth_restrict_f32(N, L, U_out, F, step, M, F_c, want_error=False):
+    err = DeviceGrid((1,)) if want_error else None
+    lib().mg_smooth_restrict_f32(N, L, None, U_out.ptr, F.ptr, step, err.ptr if err else None, M, F_c.ptr)
+    _check()
+    if want_error:
+        v = float(err.to_host()[0])
+        err.free()
+        return v
+
+
+def prolong_smooth_f32(Nc, U_c, N, L, U_in, U_out, F, step, want_error=False):
+    err = DeviceGrid((1,)) if want_error else None
+    lib().mg_prolong_smooth_f32(Nc, U_c.ptr, N, L, U_in.ptr, U_out.ptr, F.ptr, step, err.ptr if err else None)
+    _check()
+    if want_error:
+        v = float(err.to_host()[0])
+        err.free()
+        return v
+
+
 # ---------------------------------------------------------------------------------
 # the reference's operator surface (src/MG_solver_CPU.cpp:23-28) on DeviceGrid
 # ---------------------------------------------------------------------------------
@@ -365,9 +427,10 @@ class CyclePlan:
     """mg_cycle_load / mg_cycle_execute: the reference program's timed window
     (src/MG_solver_CPU.cpp:156..429) over a cycle structure file."""
 
-    def __init__(self, path, fused=True, graph=False, report=True, error=True):
+    def __init__(self, path, fused=True, graph=False, report=True, error=True, mixed=False):
         flags = ((MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) |
-                 (MG_CYCLE_REPORT if report else 0) | (MG_CYCLE_ERROR if error else 0))
+                 (MG_CYCLE_REPORT if report else 0) | (MG_CYCLE_ERROR if error else 0) |
+                 (MG_CYCLE_MIXED if mixed else 0))
         try:
             with open(path) as f:
                 head = f.read().split()[:3]

@@ -357,6 +357,8 @@ void mg_finalize(void)
         (void)hipFree(kv.second.w);
         (void)hipFree(kv.second.inv);
         (void)hipFree(kv.second.inv_w);
+        (void)hipFree(kv.second.w_f);
+        (void)hipFree(kv.second.inv_w_f);
     }
     for (auto &kv : c.ptab) {
         (void)hipFree(kv.second.owner_row);
@@ -365,6 +367,10 @@ void mg_finalize(void)
         (void)hipFree(kv.second.row_lo);
         (void)hipFree(kv.second.col_hi);
         (void)hipFree(kv.second.col_lo);
+        (void)hipFree(kv.second.row_hi_f);
+        (void)hipFree(kv.second.row_lo_f);
+        (void)hipFree(kv.second.col_hi_f);
+        (void)hipFree(kv.second.col_lo_f);
     }
     c.rtab.clear();
     c.ptab.clear();
@@ -690,6 +696,85 @@ void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double 
         MG_HIP(hipMemcpyAsync(U_out, tmp, n * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
         scratch_pool().put(tmp);
     }
+}
+
+// ------------------------------------------------------------------ mixed precision (fp32 fields)
+// The fp32 forms of the two fused nodes: every array and every arithmetic operation in fp32,
+// norms in fp64.  They exist for the streaming smoother on even N with fusable tables -- the
+// shapes a halving hierarchy produces; anything else is refused (no silent fp64 fallback).
+void mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, float *F, int step, double *error_dev,
+                            int M, float *F_c)
+{
+    if (!require_ready("mg_smooth_restrict_f32") || !grid_args_ok("mg_smooth_restrict_f32", N) ||
+        !grid_args_ok("mg_smooth_restrict_f32", M))
+        return;
+    Context &c = ctx();
+    const RestrictTable &rt = restrict_table(N, M);
+    if (!rt.lo) return;
+    if (U_in != nullptr || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !rt.fusable) {
+        fail(MG_ERR_UNSUPPORTED, "mg_smooth_restrict_f32: needs a zero start, 1..%d steps, even N and a nested coarse size (N=%d M=%d step=%d)",
+             k::stream_max_steps(), N, M, step);
+        return;
+    }
+    const double dx2 = spacing_sq(N, L);
+    const size_t n = (size_t)N * N;
+    ProfScope ps("jacobi_stream_f32<zero,res,restrict>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
+    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, nullptr, 0, nullptr, F_c,
+                         M, &rt);
+}
+
+void mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out, float *F, int step,
+                           double *error_dev)
+{
+    if (!require_ready("mg_prolong_smooth_f32") || !grid_args_ok("mg_prolong_smooth_f32", N) ||
+        !grid_args_ok("mg_prolong_smooth_f32", Nc))
+        return;
+    Context &c = ctx();
+    const ProlongTable &pt = prolong_table(Nc, N);
+    if (!pt.owner_row) return;
+    if (U_in == U_out || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !pt.fusable) {
+        fail(MG_ERR_UNSUPPORTED, "mg_prolong_smooth_f32: needs 1..%d steps, even N and a nested coarse size (Nc=%d N=%d step=%d)",
+             k::stream_max_steps(), Nc, N, step);
+        return;
+    }
+    const double dx2 = spacing_sq(N, L);
+    const size_t n = (size_t)N * N;
+    ProfScope ps("jacobi_stream_f32<prolong>", N, (double)n * (12.0 * step + 8.0) + 4.0 * Nc * Nc);
+    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,
+                         nullptr);
+}
+
+float *mg_alloc_f32(size_t n)
+{
+    if (!require_ready("mg_alloc_f32")) return nullptr;
+    return (float *)ctx().pool.get(n * sizeof(float));
+}
+void mg_free_f32(float *p)
+{
+    if (!p || !require_ready("mg_free_f32")) return;
+    ctx().pool.put(p);
+}
+void mg_to_f32(float *dst, const double *src, size_t n)
+{
+    if (!require_ready("mg_to_f32")) return;
+    k::convert_to_f32(ctx().stream, dst, src, n);
+}
+void mg_to_f64(double *dst, const float *src, size_t n)
+{
+    if (!require_ready("mg_to_f64")) return;
+    k::convert_to_f64(ctx().stream, dst, src, n);
+}
+void mg_upload_f32(float *dev, const float *host, size_t n)
+{
+    if (!require_ready("mg_upload_f32")) return;
+    hipStream_t s = ctx().stream;
+    if (MG_HIP(hipMemcpyAsync(dev, host, n * sizeof(float), hipMemcpyHostToDevice, s))) MG_HIP(hipStreamSynchronize(s));
+}
+void mg_download_f32(float *host, const float *dev, size_t n)
+{
+    if (!require_ready("mg_download_f32")) return;
+    hipStream_t s = ctx().stream;
+    if (MG_HIP(hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, s))) MG_HIP(hipStreamSynchronize(s));
 }
 
 void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *error)

@@ -36,7 +36,9 @@ struct LevelNode {  // src/linkedlist.h:4-30
 
 class LevelList {
 public:
-    explicit LevelList(Pool *pool) : pool_(pool) {}
+    // elem_bytes: 8 (fp64 fields) or 4 (the fp32 fields of the mixed-precision mode; the typed
+    // double* members then only carry the address)
+    explicit LevelList(Pool *pool, size_t elem_bytes = sizeof(double)) : pool_(pool), elem_bytes_(elem_bytes) {}
     ~LevelList() { clear(); }
     void clear()
     {
@@ -46,7 +48,7 @@ public:
     void Push_back(int n)  // src/linkedlist.cpp:28-44 (+ ListNode::ListNode :7-16)
     {
         LevelNode *nd = new LevelNode;
-        const size_t bytes = (size_t)n * n * sizeof(double);
+        const size_t bytes = (size_t)n * n * elem_bytes_;
         nd->N = n;
         nd->U = (double *)pool_->get(bytes);
         nd->F = (double *)pool_->get(bytes);
@@ -90,6 +92,7 @@ public:
 
 private:
     Pool *pool_;
+    size_t elem_bytes_;
     LevelNode *firstNode_ = nullptr, *lastNode_ = nullptr;
     int init_ = 1;  // 1 until the list has collapsed back to the first node once
 };
@@ -129,6 +132,7 @@ struct mg_cycle_plan {
     Pool pool;                       // plan-private arena (stable addresses for graph replay)
     LevelList *levels = nullptr;
     double *F_finest = nullptr;      // getSource(N_max), evaluated once at load (:153)
+    double *F64 = nullptr, *U64 = nullptr;  // mixed mode: the fp64 source and the widened result
     double *err_dev = nullptr;       // one slot per smoothing record
     size_t err_cap = 0;
     std::vector<mg_node_record> records;
@@ -204,6 +208,8 @@ bool scan_tail(const std::vector<double> &tokens, size_t *tok_io, const std::vec
         const double dx = L / (double)(a.N[l] - 1);
         a.dx2[l] = dx * dx;
         a.inv[l] = 1.0 / a.dx2[l];
+        a.gs_h2[l] = a.dx2[l];
+        a.gs_inv[l] = a.inv[l];
         if (l + 1 < a.n_levels) {
             const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
             const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
@@ -375,6 +381,42 @@ bool try_tail(Exec &x)
             report_smoothing(p, nd.err_slot);
         }
     }
+    if (p->flags & MG_CYCLE_MIXED) {
+        // the same slice with fp32 fields: spacings and transfer weights rounded to fp32
+        k::TailArgsF f;
+        memset(&f, 0, sizeof f);
+        f.n_levels = a.n_levels;
+        f.n_nodes = a.n_nodes;
+        for (int i = 0; i < a.n_nodes; ++i) f.nodes[i] = a.nodes[i];
+        for (int l = 0; l < a.n_levels; ++l) {
+            f.N[l] = a.N[l];
+            f.dx2[l] = (float)a.dx2[l];
+            f.inv[l] = (float)a.inv[l];
+            f.gs_h2[l] = a.dx2[l];
+            f.gs_inv[l] = a.inv[l];
+            if (l + 1 < a.n_levels) {
+                const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
+                const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
+                f.r_lo[l] = rt.lo;
+                f.r_w[l] = rt.w_f;
+                f.p_orow[l] = pt.owner_row;
+                f.p_ocol[l] = pt.owner_col;
+                f.p_rhi[l] = pt.row_hi_f;
+                f.p_rlo[l] = pt.row_lo_f;
+                f.p_chi[l] = pt.col_hi_f;
+                f.p_clo[l] = pt.col_lo_f;
+                f.c_dx[l] = (float)pt.c_dx;
+            }
+        }
+        f.F_top = (const float *)top->F;
+        f.U_top = (float *)top->U;
+        f.err_dev = p->err_dev;
+        f.gs_state = x.c.gs_state;
+        ProfScope ps("coarse_tail_f32", top->N, 0.0);
+        k::tail_launch_f32(x.c.stream, f);
+        x.tok = tok;
+        return true;
+    }
     a.F_top = top->F;
     a.U_top = top->U;
     a.err_dev = p->err_dev;
@@ -393,6 +435,7 @@ void run_nodes(Exec &x)
     mg_cycle_plan *p = x.p;
     LevelList &cycle = *p->levels;
     const bool fused = (p->flags & MG_CYCLE_FUSED) != 0;
+    const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0;
     x.c.defer_norms = true;
 
     for (;;) {
@@ -429,6 +472,19 @@ void run_nodes(Exec &x)
                 cycle.Push_back(next_N);  // :283
                 if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
                 mg_restrict_signed(lv->N, lv->D, next_N, cycle.last()->F, +1);  // :287
+            } else if (mixed) {
+                // the same fused node with fp32 fields (zero start only: no restart in this mode)
+                if (keep) { x.status = 15; break; }
+                rec = add_record(p, -1, lv->N, step);
+                report_smoothing(p, rec);
+                cycle.Push_back(next_N);  // :283
+                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }
+                mg_smooth_restrict_f32(lv->N, p->L, nullptr, (float *)lv->U, (float *)lv->F, step, error_slot(p, rec), next_N,
+                                       (float *)cycle.last()->F);
+                if (x.c.last_error) { x.status = 15; break; }
+                report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
+                if (!try_tail(x) && next_N <= k::TAIL_MAX_N) { x.status = 15; break; }
+                continue;
             } else if (fused) {
                 // smoothing (:259), residual (:268), sign flip (:277-280) and restriction (:287)
                 // in one pass; the zero fill of U (:256) is folded into the first sweep
@@ -462,6 +518,7 @@ void run_nodes(Exec &x)
             int option;
             if (!x.next(&tol) || !x.next_int(&option)) { x.status = 3; break; }
             LevelNode *lv = cycle.last();
+            if (mixed) { x.status = 15; break; }  // fp32 coarse solves exist inside the tail kernel only
             if (x.capturing && lv->N > k::gs_single_workgroup_max_n()) { x.status = 8; break; }
             mg_doExactSolver(lv->N, p->L, lv->U, lv->F, tol, option);
             if (x.c.last_error) { x.status = 5; break; }
@@ -485,6 +542,18 @@ void run_nodes(Exec &x)
             LevelNode *coarse = cycle.last();
             LevelNode *fine = coarse->prevNode;
             const char *arrow = "             *\n             |\nProlongation |\n             |\n             *\n";
+            if (mixed) {
+                if (step <= 0) { x.status = 15; break; }
+                const int rec = add_record(p, 1, fine->N, step);
+                mg_prolong_smooth_f32(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, (float *)fine->D,
+                                      (float *)fine->F, step, error_slot(p, rec));
+                if (x.c.last_error) { x.status = 15; break; }
+                std::swap(fine->U, fine->D);
+                cycle.Remove_back();  // :363
+                report_text(p, arrow);
+                report_smoothing(p, rec);
+                continue;
+            }
             if (fused && step > 0) {
                 // tempU (:353), doProlongation (:354), doGridAddition (:368) and the post-smoothing
                 // (:416) in one pass; the fine level's D is dead here and receives the result
@@ -594,14 +663,35 @@ mg_cycle_plan *mg_cycle_load(const char *path, int flags)
         if (t == -1.0 || t == 1.0) ++smoothing_nodes;
     p->err_cap = smoothing_nodes + 8;
     p->err_dev = (double *)p->pool.get(p->err_cap * sizeof(double));
-    p->levels = new LevelList(&p->pool);
+    const bool mixed = (flags & MG_CYCLE_MIXED) != 0;
+    if (mixed && (!(flags & MG_CYCLE_FUSED) || p->con_N != 1 || p->con_step < 1 || p->con_step > k::stream_max_steps())) {
+        fail(MG_ERR_UNSUPPORTED, "%s: the mixed-precision mode needs the fused driver, con_N = 1 and a fixed con_step in 1..%d",
+             path, k::stream_max_steps());
+        delete p;
+        return nullptr;
+    }
+    p->levels = new LevelList(&p->pool, mixed ? sizeof(float) : sizeof(double));
     p->levels->Push_back(p->N_max);  // :149
     LevelNode *top = p->levels->last();
     if (!top->U || !top->F || !top->D || !p->err_dev) {
         mg_cycle_destroy(p);
         return nullptr;
     }
-    mg_getSource(top->N, p->L, top->F, p->min_x, p->min_y);  // :153
+    if (mixed) {
+        // F is evaluated in fp64 exactly as always and rounded to fp32 ONCE; the result comes back
+        // widened into an fp64 array
+        const size_t n = (size_t)top->N * top->N;
+        p->F64 = (double *)p->pool.get(n * sizeof(double));
+        p->U64 = (double *)p->pool.get(n * sizeof(double));
+        if (!p->F64 || !p->U64) {
+            mg_cycle_destroy(p);
+            return nullptr;
+        }
+        mg_getSource(top->N, p->L, p->F64, p->min_x, p->min_y);  // :153
+        mg_to_f32((float *)top->F, p->F64, n);
+    } else {
+        mg_getSource(top->N, p->L, top->F, p->min_x, p->min_y);  // :153
+    }
     p->F_finest = top->F;
     (void)hipEventCreate(&p->ev0);
     (void)hipEventCreate(&p->ev1);
@@ -617,8 +707,8 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     if (!require_ready("mg_cycle_enqueue") || !p) return 1;
     Context &c = ctx();
     hipStream_t s = c.stream;
-    const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !uses_trigger(p) &&
-                            !p->graph_failed;
+    const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
+                            !uses_trigger(p) && !p->graph_failed;
     int status = 0;
     (void)hipEventRecord(p->ev0, s);
 
@@ -661,6 +751,10 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         LevelNode *last = p->levels->last();
         p->final_U = last->U;
         p->final_N = last->N;
+        if ((p->flags & MG_CYCLE_MIXED) && status == 0 && last->N == p->N_max) {
+            k::convert_to_f64(s, p->U64, (const float *)last->U, (size_t)last->N * last->N);
+            p->final_U = p->U64;
+        }
     }
     (void)hipEventRecord(p->ev1, s);
     p->last_status = status;
@@ -745,6 +839,8 @@ void mg_cycle_destroy(mg_cycle_plan *p)
         delete p->levels;
     }
     if (p->err_dev) p->pool.put(p->err_dev);
+    if (p->F64) p->pool.put(p->F64);
+    if (p->U64) p->pool.put(p->U64);
     p->pool.trim();
     delete p;
 }

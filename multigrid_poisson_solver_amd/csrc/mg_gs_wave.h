@@ -53,12 +53,20 @@ __device__ __forceinline__ double wave_total(double v)
     return ((read_lane(v, 15) + read_lane(v, 31)) + read_lane(v, 47)) + read_lane(v, 63);
 }
 
-struct Neighbours {
-    double w, e, n, s;
-};
-__device__ __forceinline__ Neighbours fetch(double u, int l_n, int l_s)
+__device__ __forceinline__ float lane_shift(float v, int dpp_ctrl_is_shr)
 {
-    Neighbours nb;
+    if (dpp_ctrl_is_shr) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+template <typename T>
+struct Neighbours {
+    T w, e, n, s;
+};
+template <typename T>
+__device__ __forceinline__ Neighbours<T> fetch(T u, int l_n, int l_s)
+{
+    Neighbours<T> nb;
     nb.w = lane_shift(u, 1);   // lane - 1
     nb.e = lane_shift(u, 0);   // lane + 1
     nb.n = __shfl(u, l_n, 64); // lane + N
@@ -68,33 +76,37 @@ __device__ __forceinline__ Neighbours fetch(double u, int l_n, int l_s)
 
 // all 64 lanes of the wave must call this; lanes >= N*N idle along.  f = F at this lane's point
 // (0 for idle lanes).  Returns this lane's U; *iterations_out = number of iterations run.
-__device__ __forceinline__ double solve(int N, double h2, double inv, double f, double tol, int max_iter, int *iterations_out)
+// T = field type (double, or float in the mixed-precision mode); the norm and the convergence
+// test are fp64 either way.
+template <typename T>
+__device__ __forceinline__ T solve(int N, T h2, T inv, T f, double tol, int max_iter, int *iterations_out)
 {
     const int lane = threadIdx.x & 63;
     const int n = N * N;
     const int r = lane / N, c = lane - r * N;
     const bool inside = lane < n && !(r == 0 || c == 0 || r == N - 1 || c == N - 1);
     const int colour = (r + c) & 1;
-    const double h2f = h2 * f;
+    const T h2f = h2 * f;
     const int l_s = lane >= N ? lane - N : 0, l_n = lane + N < 64 ? lane + N : 63;
     const double denom = (double)((N - 2) * (N - 2));
-    double u = 0.0;  // memset(U, 0)  :993
-    Neighbours nb = fetch(u, l_n, l_s);
+    T u = 0.0;  // memset(U, 0)  :993
+    Neighbours<T> nb = fetch(u, l_n, l_s);
     int iterations = 0;
     for (;;) {
         // red: U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F)  :1020
         {
-            const double nu = 0.25 * (nb.w + nb.e + nb.n + nb.s - h2f);
+            const T nu = T(0.25) * (nb.w + nb.e + nb.n + nb.s - h2f);
             if (inside && colour == 0) u = nu;
         }
         nb = fetch(u, l_n, l_s);
         {   // black :1043
-            const double nu = 0.25 * (nb.w + nb.e + nb.n + nb.s - h2f);
+            const T nu = T(0.25) * (nb.w + nb.e + nb.n + nb.s - h2f);
             if (inside && colour == 1) u = nu;
         }
         ++iterations;
         nb = fetch(u, l_n, l_s);  // serves the norm now and the next red pass
-        const double res = inside ? fabs(inv * (nb.n + nb.s + nb.e + nb.w - 4 * u) - f) : 0.0;  // :560
+        const T rs = inv * (nb.n + nb.s + nb.e + nb.w - 4 * u) - f;  // :560
+        const double res = inside ? fabs((double)rs) : 0.0;
         const double err = wave_total(res) / denom;                                             // :1059
         if (!(err > tol) || iterations >= max_iter) break;
     }

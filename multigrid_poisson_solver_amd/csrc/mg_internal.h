@@ -41,12 +41,14 @@ struct RestrictTable {
     double *w = nullptr;   // [M] weight a (resp. c)
     int *inv = nullptr;    // [N] fine index -> interior coarse index with lo[] == it, else -1
     double *inv_w = nullptr; // [N] w[inv[x]] (0 where inv[x] < 0)
+    float *w_f = nullptr, *inv_w_f = nullptr;  // the same weights rounded to fp32 (mixed-precision mode)
     bool fusable = false;  // lo[] strictly increasing by >= 2: one coarse sample per column pair
 };
 struct ProlongTable {
     int *owner_row = nullptr, *owner_col = nullptr;        // [M]
     double *row_hi = nullptr, *row_lo = nullptr;           // [M] (c3y - f_y), (f_y - c1y)
     double *col_hi = nullptr, *col_lo = nullptr;           // [M] (c2x - f_x), (f_x - c1x)
+    float *row_hi_f = nullptr, *row_lo_f = nullptr, *col_hi_f = nullptr, *col_lo_f = nullptr;  // rounded to fp32
     double c_dx = 0.0;
     bool fusable = false;  // every fine index owned, owners advance by <= 1 per fine index
 };
@@ -200,6 +202,8 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);
+void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n);
+void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n);
 void add(hipStream_t s, size_t n, double *a, const double *b);
 void negate(hipStream_t s, size_t n, double *a);
 void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y);
@@ -210,6 +214,11 @@ void analytic_error_rows(hipStream_t s, int N, double L, const double *U, const 
                          double min_y, double *out_raw);
 void fill_uniform(hipStream_t s, double *dst, size_t n, uint64_t seed);
 void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2]*/);
+// fp32 instantiation of the streaming smoother (mg_stream_f32.hip): zero start or prolongation input,
+// optional restriction output; whole grid local
+void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
+                       double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
+                       const RestrictTable *rt);
 // coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
 constexpr int TAIL_MAX_LEVELS = 6;
 constexpr int TAIL_MAX_NODES = 48;
@@ -221,21 +230,26 @@ struct TailNode {
     int pad;
     double tol;    // exact-solver target (0)
 };
-struct TailArgs {
+template <typename T>
+struct TailArgsT {
     int n_levels, n_nodes;
     int N[TAIL_MAX_LEVELS];
-    double dx2[TAIL_MAX_LEVELS], inv[TAIL_MAX_LEVELS];
+    T dx2[TAIL_MAX_LEVELS], inv[TAIL_MAX_LEVELS];
+    double gs_h2[TAIL_MAX_LEVELS], gs_inv[TAIL_MAX_LEVELS];  // fp64 spacings: the exact solver is fp64 in every mode
     const int *r_lo[TAIL_MAX_LEVELS];      // restriction level l -> l+1
-    const double *r_w[TAIL_MAX_LEVELS];
+    const T *r_w[TAIL_MAX_LEVELS];
     const int *p_orow[TAIL_MAX_LEVELS], *p_ocol[TAIL_MAX_LEVELS];  // prolongation level l+1 -> l
-    const double *p_rhi[TAIL_MAX_LEVELS], *p_rlo[TAIL_MAX_LEVELS], *p_chi[TAIL_MAX_LEVELS], *p_clo[TAIL_MAX_LEVELS];
-    double c_dx[TAIL_MAX_LEVELS];
-    const double *F_top;
-    double *U_top;
-    double *err_dev;
+    const T *p_rhi[TAIL_MAX_LEVELS], *p_rlo[TAIL_MAX_LEVELS], *p_chi[TAIL_MAX_LEVELS], *p_clo[TAIL_MAX_LEVELS];
+    T c_dx[TAIL_MAX_LEVELS];
+    const T *F_top;
+    T *U_top;
+    double *err_dev;   // norms are fp64 whatever the field type
     int *gs_state;
     TailNode nodes[TAIL_MAX_NODES];
 };
+typedef TailArgsT<double> TailArgs;
+typedef TailArgsT<float> TailArgsF;
+void tail_launch_f32(hipStream_t s, const TailArgsF &a);
 bool tail_fits(const TailArgs &a);
 void tail_launch(hipStream_t s, const TailArgs &a);
 // red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]

@@ -251,6 +251,16 @@ __global__ __launch_bounds__(TB) void k_negate(size_t n, double *__restrict__ a)
     for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) a[i] = -a[i];
 }
 
+// fp64 <-> fp32 (mixed-precision mode): round to nearest / exact widening
+__global__ __launch_bounds__(TB) void k_to_f32(float *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) dst[i] = (float)src[i];
+}
+__global__ __launch_bounds__(TB) void k_to_f64(double *__restrict__ dst, const float *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) dst[i] = (double)src[i];
+}
+
 // ---------------------------------------------------------------- problem definition
 // src/MG_solver_CPU.cpp:488 / :544.  Device exp() is within 1 ulp of libm's, so these
 // are NOT bit-identical to the host evaluation; the driver uses the host form for F.
@@ -549,6 +559,15 @@ void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in,
     else
         hipLaunchKernelGGL(k_prolong<false>, g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
                            t.row_hi, t.row_lo, t.col_hi, t.col_lo, t.c_dx);
+}
+
+void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n)
+{
+    hipLaunchKernelGGL(k_to_f32, dim3(grid_flat(n)), dim3(TB), 0, s, dst, src, n);
+}
+void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n)
+{
+    hipLaunchKernelGGL(k_to_f64, dim3(grid_flat(n)), dim3(TB), 0, s, dst, src, n);
 }
 
 void add(hipStream_t s, size_t n, double *a, const double *b)

@@ -121,6 +121,9 @@ const RestrictTable &restrict_table(int N, int M)
         }
         t.inv = upload(inv);
         t.inv_w = upload(inv_w);
+        std::vector<float> w_f(w.begin(), w.end()), inv_w_f(inv_w.begin(), inv_w.end());  // RN to fp32
+        t.w_f = upload(w_f);
+        t.inv_w_f = upload(inv_w_f);
         t.fusable = ok;
     }
     return c.rtab.emplace(key, t).first->second;
@@ -153,6 +156,11 @@ const ProlongTable &prolong_table(int N, int M)
         t.row_lo = upload(rl);
         t.col_hi = upload(ch);
         t.col_lo = upload(cl);
+        std::vector<float> rhf(rh.begin(), rh.end()), rlf(rl.begin(), rl.end()), chf(ch.begin(), ch.end()), clf(cl.begin(), cl.end());
+        t.row_hi_f = upload(rhf);
+        t.row_lo_f = upload(rlf);
+        t.col_hi_f = upload(chf);
+        t.col_lo_f = upload(clf);
         t.c_dx = 1.0 / (double)(N - 1);
         t.fusable = fusable;
     }

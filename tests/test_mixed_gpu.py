@@ -1,0 +1,73 @@
+"""The mixed-precision mode: fp32 fields and arithmetic for the whole
+cycle, fp64 source rounded once, result widened to fp64.  The HIP kernels are held bit for bit to
+the numpy fp32 restatement (tests/_oracle_f32.py, "parity unpinned": the reference's fp32 path is
+CUDA-only) and, against the fp64 oracle, to a stated tolerance."""
+import numpy as np
+import pytest
+
+import _oracle_f32 as o32
+
+pytestmark = pytest.mark.gpu
+
+
+def bits32(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return a.shape == b.shape and np.array_equal((a + np.float32(0)).view(np.uint32), (b + np.float32(0)).view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [8, 16, 64, 256, 1024])
+@pytest.mark.parametrize("step", [1, 3, 4])
+def test_fused_nodes_fp32_vs_numpy(mg, N, step):
+    M = N // 2
+    rng = np.random.default_rng(N + step)
+    F = (rng.random((N, N)) - 0.5).astype(np.float32)
+    Fd, Uo, Fc = mg.DeviceGrid32.from_host(F), mg.DeviceGrid32((N, N)), mg.DeviceGrid32((M, M))
+    err = mg.smooth_restrict_f32(N, 1.0, Uo, Fd, step, M, Fc, want_error=True)
+    U, e = o32.smooth(np.zeros((N, N), dtype=np.float32), F, step, 1.0)
+    assert bits32(Uo.to_host(), U), f"fp32 smoothing N={N} step={step}"
+    assert err == pytest.approx(e, rel=1e-12)
+    assert bits32(Fc.to_host(), o32.restrict_neg_residual(mg, U, F, 1.0, M)), "fp32 fused restriction"
+    if M >= 4:
+        Uc = (rng.random((M, M)) - 0.5).astype(np.float32)
+        Uf = rng.random((N, N)).astype(np.float32)
+        out = mg.DeviceGrid32((N, N))
+        err = mg.prolong_smooth_f32(M, mg.DeviceGrid32.from_host(Uc), N, 1.0, mg.DeviceGrid32.from_host(Uf), out, Fd, step,
+                                    want_error=True)
+        want, e = o32.smooth(o32.prolong_add(mg, Uc, Uf), F, step, 1.0)
+        assert bits32(out.to_host(), want), f"fp32 prolong+smooth {M}->{N}"
+        assert err == pytest.approx(e, rel=1e-12)
+
+
+@pytest.mark.parametrize("kind,N,n_min", [("V", 256, 8), ("W", 128, 8), ("V", 1024, 8), ("V", 512, 32)])
+def test_mixed_cycle_vs_numpy_and_fp64(mg, oracle, tmp_path, kind, N, n_min):
+    path = str(tmp_path / "c.txt")
+    (mg.write_vcycle_file if kind == "V" else mg.write_wcycle_file)(path, N, n_min, 3, 1e-7)
+    toks = open(path).read().split()
+    sizes, n = [], N
+    while n >= n_min:
+        sizes.append(n)
+        n //= 2
+    F64 = oracle.getSource(N)
+    U32, recs = o32.run_cycle_tokens(mg, oracle, F64, 1.0, 3, sizes, toks[7:])
+    plan = mg.CyclePlan(path, fused=True, mixed=True)
+    got = plan.execute(fetch_U=True)
+    assert got["status"] == 0
+    assert bits32(got["U"].astype(np.float32), U32), "mixed cycle: fp32 result"
+    assert np.array_equal(got["U"], U32.astype(np.float64)), "widening is exact"
+    assert len(got["records"]) == len(recs)
+    for g, w in zip(got["records"], recs):
+        assert (g[0], g[1]) == (w[0], w[1])
+        assert g[3] == pytest.approx(w[2], rel=1e-10, abs=1e-300)
+    # against the fp64 cycle of the reference: fp32 rounding only (tolerance 2e-5 of max|U|)
+    want = oracle.run_cycle_file(path)
+    scale = np.abs(want["U"]).max()
+    assert np.abs(got["U"] - want["U"]).max() <= 2e-5 * scale
+    assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-3)
+    plan.close()
+
+
+def test_mixed_mode_refuses_unsupported_shapes(mg, tmp_path):
+    trig = tmp_path / "t.txt"
+    trig.write_text("\n".join(["1.0 0.0 0.0", "-1 1", "64 8", "-1", "-1", "0", "0.0000001 1", "1", "1", "2"]))
+    with pytest.raises(mg.MGError, match="mixed-precision"):
+        mg.CyclePlan(str(trig), mixed=True)
