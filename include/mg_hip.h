@@ -205,6 +205,12 @@ int            mg_cycle_execute(mg_cycle_plan *plan, mg_cycle_result *out);
  * (waits, reports the last one).  mg_cycle_execute == sync + enqueue + sync + collect. */
 int            mg_cycle_enqueue(mg_cycle_plan *plan);
 int            mg_cycle_collect(mg_cycle_plan *plan, mg_cycle_result *out);
+/* MG_CYCLE_MIXED plans: `cycles` fp32 runs of the file per window, joined by the fp64 residual of
+ * the fp64 iterate and an fp64 correction (iterative refinement; BASELINE.json configs[4]).  The
+ * errors are doSmoothing's metric (src/MG_solver_CPU.cpp:607-622) of the iterate after 1 .. cycles-1
+ * corrections. */
+int            mg_cycle_set_refinement(mg_cycle_plan *plan, int cycles);
+int            mg_cycle_refinement_errors(mg_cycle_plan *plan, double *out, int cap);
 void           mg_cycle_destroy(mg_cycle_plan *plan);
 /* the whole reference program: load, execute, print report, write Sol_HIP_<file> CSV */
 int            mg_cycle_main(int argc, char **argv);

@@ -60,6 +60,7 @@ ABI = {
     "mg_smooth_pp": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "mg_smooth_restrict": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "mg_prolong_smooth": (None, [_i, _vp, _i, _d, _vp, _vp, _vp, _i, _vp]),
+    "mg_cycle_set_refinement": (_i, [_vp, _i]), "mg_cycle_refinement_errors": (_i, [_vp, _vp, _i]),
     "mg_smooth_restrict_f32": (None, [_i, _d, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "mg_prolong_smooth_f32": (None, [_i, _vp, _i, _d, _vp, _vp, _vp, _i, _vp]),
     "mg_alloc_f32": (_vp, [_sz]), "mg_free_f32": (None, [_vp]), "mg_to_f32": (None, [_vp, _vp, _sz]),
@@ -427,7 +428,7 @@ class CyclePlan:
     """mg_cycle_load / mg_cycle_execute: the reference program's timed window
     (src/MG_solver_CPU.cpp:156..429) over a cycle structure file."""
 
-    def __init__(self, path, fused=True, graph=False, report=True, error=True, mixed=False):
+    def __init__(self, path, fused=True, graph=False, report=True, error=True, mixed=False, refinement=1):
         flags = ((MG_CYCLE_FUSED if fused else 0) | (MG_CYCLE_GRAPH if graph else 0) |
                  (MG_CYCLE_REPORT if report else 0) | (MG_CYCLE_ERROR if error else 0) |
                  (MG_CYCLE_MIXED if mixed else 0))
@@ -441,6 +442,10 @@ class CyclePlan:
         _check()
         if not self._plan:
             raise MGError(f"cannot load cycle file {path}")
+        self.refinement = refinement
+        if refinement != 1:
+            _lib.mg_cycle_set_refinement(self._plan, refinement)
+            _check()
 
     def enqueue(self):
         """One window on the engine's stream, no host synchronisation (see collect)."""
@@ -463,6 +468,10 @@ class CyclePlan:
             U = np.empty((res.N, res.N))
             _lib.mg_download(U.ctypes.data, res.U_dev, U.size)
             out["U"] = U
+        if self.refinement > 1:
+            e = np.zeros(self.refinement - 1)
+            n = _lib.mg_cycle_refinement_errors(self._plan, e.ctypes.data, e.size)
+            out["refinement_errors"] = e[:n].tolist()
         return out
 
     def analytic_error(self, result):

@@ -78,6 +78,7 @@ public:
         delete nd;
     }
     LevelNode *last() { return lastNode_; }
+    LevelNode *first() { return firstNode_; }
     int depth() const
     {
         int d = 0;
@@ -133,6 +134,10 @@ struct mg_cycle_plan {
     LevelList *levels = nullptr;
     double *F_finest = nullptr;      // getSource(N_max), evaluated once at load (:153)
     double *F64 = nullptr, *U64 = nullptr;  // mixed mode: the fp64 source and the widened result
+    int refinements = 1;             // mixed mode: fp32 cycles per window (fp64 residual + correction between them)
+    bool F32_stale = false;          // the finest fp32 F holds a residual, not the rounded source
+    double *refine_err_dev = nullptr;
+    std::vector<double> refine_err;
     double *err_dev = nullptr;       // one slot per smoothing record
     size_t err_cap = 0;
     std::vector<mg_node_record> records;
@@ -717,8 +722,23 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         // only the error values are refreshed at collect time.
         if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
     } else {
-        reset_levels(p);
+        const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0;
+        const int outer = mixed ? p->refinements : 1;
+        const size_t n_top = (size_t)p->N_max * p->N_max;
+        if (mixed && p->F32_stale) {  // a previous window left a residual in the fp32 source
+            k::convert_to_f32(s, (float *)p->levels->first()->F, p->F64, n_top);
+            p->F32_stale = false;
+        }
+        for (int it = 0; it < outer && status == 0; ++it) {
+        reset_levels(p);  // records/report: those of the last fp32 cycle
         c.active_pool = &p->pool;
+        if (it > 0) {
+            // fp64 residual of the fp64 iterate -> fp32 source of the next correction cycle
+            const double dx = p->L / (double)(p->N_max - 1);
+            k::refine_residual(s, p->N_max, 1.0 / (dx * dx), p->U64, p->F64, (float *)p->levels->first()->F,
+                               p->refine_err_dev + (it - 1));
+            p->F32_stale = true;
+        }
         Exec x{p, c};
         const bool capture_now = want_graph && p->warm_runs >= 1;  // run 0 warms pool + tables
         if (capture_now) {
@@ -751,9 +771,14 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         LevelNode *last = p->levels->last();
         p->final_U = last->U;
         p->final_N = last->N;
-        if ((p->flags & MG_CYCLE_MIXED) && status == 0 && last->N == p->N_max) {
-            k::convert_to_f64(s, p->U64, (const float *)last->U, (size_t)last->N * last->N);
+        if (mixed && status == 0 && last->N == p->N_max) {
+            // fp64 correction: U64 = (double)e on the first cycle, U64 += (double)e afterwards
+            if (it == 0) k::convert_to_f64(s, p->U64, (const float *)last->U, n_top);
+            else k::add_widened(s, p->U64, (const float *)last->U, n_top);
             p->final_U = p->U64;
+        } else if (mixed && status == 0) {
+            status = 15;  // the file does not come back to the finest level: nothing to widen
+        }
         }
     }
     (void)hipEventRecord(p->ev1, s);
@@ -777,6 +802,12 @@ int mg_cycle_collect(mg_cycle_plan *p, mg_cycle_result *out)
         mg_download(all.data(), p->err_dev, all.size());
         for (size_t i = 0; i < p->records.size(); ++i)
             if (p->records[i].node != 0) p->records[i].error = all[i];
+    }
+
+    p->refine_err.clear();
+    if ((p->flags & MG_CYCLE_MIXED) && p->refinements > 1 && p->refine_err_dev) {
+        p->refine_err.resize((size_t)p->refinements - 1);
+        mg_download(p->refine_err.data(), p->refine_err_dev, p->refine_err.size());
     }
 
     double mg_error = 0.0;  // outside the reference's timed window as well (:434-445)
@@ -826,6 +857,34 @@ int mg_cycle_execute(mg_cycle_plan *p, mg_cycle_result *out)
     return status;
 }
 
+// mixed-precision mode: `cycles` fp32 runs of the cycle file per window, joined by the fp64
+// residual of the fp64 iterate and an fp64 correction (BASELINE.json configs[4]: "mixed fp32
+// smoothing / fp64 residual correction").  cycles = 1 is the plain fp32 cycle.
+int mg_cycle_set_refinement(mg_cycle_plan *p, int cycles)
+{
+    if (!require_ready("mg_cycle_set_refinement") || !p) return 1;
+    if (!(p->flags & MG_CYCLE_MIXED) || cycles < 1 || cycles > 64) {
+        fail(MG_ERR_ARG, "mg_cycle_set_refinement: needs a MG_CYCLE_MIXED plan and 1..64 cycles (got %d)", cycles);
+        return 1;
+    }
+    if (!p->refine_err_dev) {
+        p->refine_err_dev = (double *)p->pool.get(64 * sizeof(double));
+        if (!p->refine_err_dev) return 1;
+    }
+    p->refinements = cycles;
+    return 0;
+}
+
+// doSmoothing's error metric (:607-622) of the fp64 iterate after 1, 2, ... cycles-1 corrections
+// (evaluated where the refinement forms its residual); returns how many were written
+int mg_cycle_refinement_errors(mg_cycle_plan *p, double *out, int cap)
+{
+    if (!p || !out) return 0;
+    int n = 0;
+    for (; n < (int)p->refine_err.size() && n < cap; ++n) out[n] = p->refine_err[(size_t)n];
+    return n;
+}
+
 void mg_cycle_destroy(mg_cycle_plan *p)
 {
     if (!p) return;
@@ -839,6 +898,7 @@ void mg_cycle_destroy(mg_cycle_plan *p)
         delete p->levels;
     }
     if (p->err_dev) p->pool.put(p->err_dev);
+    if (p->refine_err_dev) p->pool.put(p->refine_err_dev);
     if (p->F64) p->pool.put(p->F64);
     if (p->U64) p->pool.put(p->U64);
     p->pool.trim();

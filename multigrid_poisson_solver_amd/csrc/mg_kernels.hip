@@ -152,6 +152,40 @@ __global__ __launch_bounds__(TB) void k_smoothing_error(int N, double inv, const
     if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// mixed-precision refinement: the fp64 residual of the fp64 iterate, handed to the fp32 cycle as its
+// source, src = (float)(-(A U - F)), and the doSmoothing error metric (:607-622) of the iterate
+__global__ __launch_bounds__(TB) void k_refine_residual(int N, double inv, const double *__restrict__ U,
+                                                        const double *__restrict__ F, float *__restrict__ src,
+                                                        double *__restrict__ part)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    const int r0 = blockIdx.y * ROWS_PB;
+    double acc = 0.0;
+    if (c < N) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PB; ++k) {
+            const int r = r0 + k;
+            if (r >= N) break;
+            const size_t p = (size_t)r * N + c;
+            double v = 0.0;
+            if (!rim(r, c, N)) {
+                v = inv * star_minus4(U, p, N) - F[p];
+                if (((r + c) & 1) == 0) acc += fabs(v);
+            }
+            src[p] = (float)(-v);
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// U += (double)e: the fp64 correction step of the refinement
+__global__ __launch_bounds__(TB) void k_add_widened(double *__restrict__ U, const float *__restrict__ e, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) U[i] = U[i] + (double)e[i];
+}
+
 enum FinishMode { FIN_SMOOTH_ERR = 0, FIN_MEAN_NN = 1, FIN_RAW = 2 };
 
 // second stage of every norm: fixed-order sum of the per-block partials
@@ -568,6 +602,19 @@ void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n)
 void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n)
 {
     hipLaunchKernelGGL(k_to_f64, dim3(grid_flat(n)), dim3(TB), 0, s, dst, src, n);
+}
+
+void refine_residual(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, double *err_out)
+{
+    const dim3 g = grid_rows(N, ROWS_PB);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    hipLaunchKernelGGL(k_refine_residual, g, dim3(TB), 0, s, N, inv, U, F, src, part);
+    finish(s, part, np, FIN_SMOOTH_ERR, N, err_out);
+}
+void add_widened(hipStream_t s, double *U, const float *e, size_t n)
+{
+    hipLaunchKernelGGL(k_add_widened, dim3(grid_flat(n)), dim3(TB), 0, s, U, e, n);
 }
 
 void add(hipStream_t s, size_t n, double *a, const double *b)

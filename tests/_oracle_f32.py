@@ -117,3 +117,24 @@ def run_cycle_tokens(mgmod, oracle, F64, L, steps, sizes, tokens):
             fine["U"], e = smooth(prolong_add(mgmod, coarse["U"], fine["U"]), fine["F"], steps, L)
             records.append((1, fine["N"], e))
     return levels[0]["U"], records
+
+
+def refine(mgmod, oracle, F64, L, steps, sizes, tokens, cycles):
+    """`cycles` fp32 runs of the node stream joined by the fp64 residual of the fp64 iterate and an
+    fp64 correction (mg_cycle_set_refinement).  Returns (U64, errors of the iterates 1..cycles-1)."""
+    N = sizes[0]
+    U = None
+    errs = []
+    for it in range(cycles):
+        if it == 0:
+            src = F64
+        else:
+            D = oracle.getResidual(N, L, U, F64)          # A U - F, rim 0
+            rows, cols = np.indices(D.shape)
+            even = ((rows + cols) % 2 == 0)
+            s = np.abs(D[even]).sum()
+            errs.append((s + s) / N / N)
+            src = -D
+        e32, _ = run_cycle_tokens(mgmod, oracle, src, L, steps, sizes, tokens)
+        U = e32.astype(np.float64) if it == 0 else U + e32.astype(np.float64)
+    return U, errs
