@@ -226,6 +226,19 @@ int            mg_print2File(int N, const double *U_dev, const char *file_name);
 int  mg_comm_unique_id_bytes(void);
 int  mg_comm_get_unique_id(void *out);
 int  mg_comm_init(int rank, int nranks, const void *unique_id);
+/* Host-staged transport instead of RCCL: the slab driver's ghost-row groups and its all-gather are
+ * handed to two callbacks of the embedding program (MPI, gloo, ...) with HOST buffers.  `exchange`
+ * receives the n_ops point-to-point operations of one group (is_send[i], peer[i], buf[i],
+ * count[i] doubles) and returns 0 when ALL of them have completed; operations between two ranks
+ * are posted in the same order on both sides.  `allgather` fills recv[r*count .. ] with rank r's
+ * `send`.  Purpose: running the real rank-mode driver with several processes on one GPU (RCCL
+ * allows one rank per device), and clusters without xGMI.  Arithmetic stays on the device. */
+typedef struct mg_host_transport {
+    void *user;
+    int (*exchange)(void *user, int n_ops, const int *is_send, const int *peer, void *const *buf, const size_t *count);
+    int (*allgather)(void *user, const double *send, double *recv, size_t count_per_rank);
+} mg_host_transport;
+int  mg_comm_init_host(int rank, int nranks, const mg_host_transport *transport);
 void mg_comm_finalize(void);
 int  mg_comm_rank(void);
 int  mg_comm_size(void);

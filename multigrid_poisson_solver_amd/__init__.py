@@ -76,6 +76,7 @@ ABI = {
     "mg_cycle_destroy": (None, [_vp]), "mg_cycle_main": (_i, [_i, C.POINTER(C.c_char_p)]),
     "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
     "mg_comm_unique_id_bytes": (_i, []), "mg_comm_get_unique_id": (_i, [_vp]),
+    "mg_comm_init_host": (_i, [_i, _i, _vp]),
     "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_rank": (_i, []),
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
@@ -516,6 +517,50 @@ def comm_init(rank, nranks, unique_id_bytes):
     if lib().mg_comm_init(rank, nranks, buf) != 0:
         _check()
         raise MGError("mg_comm_init failed")
+    _check()
+
+
+_EXCHANGE_CB = C.CFUNCTYPE(_i, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz))
+_ALLGATHER_CB = C.CFUNCTYPE(_i, _vp, _vp, _vp, _sz)
+
+
+class HostTransport(C.Structure):
+    _fields_ = [("user", _vp), ("exchange", _EXCHANGE_CB), ("allgather", _ALLGATHER_CB)]
+
+
+_host_transport_keepalive = []
+
+
+def comm_init_host(rank, nranks, exchange, allgather):
+    """mg_comm_init_host with Python callables:
+    exchange(ops) with ops = [(is_send, peer, float64 ndarray view of the host buffer), ...] must
+    complete every transfer before returning; allgather(send, recv) fills recv (nranks x count)."""
+
+    def _exchange(_user, n, is_send, peer, buf, count):
+        try:
+            ops = [(bool(is_send[i]), int(peer[i]),
+                    np.ctypeslib.as_array(C.cast(buf[i], C.POINTER(_d)), shape=(int(count[i]),))) for i in range(n)]
+            exchange(ops)
+            return 0
+        except Exception as e:  # never unwind through the C frame
+            print(f"host transport exchange failed: {e!r}", flush=True)
+            return 1
+
+    def _allgather(_user, send, recv, count):
+        try:
+            a = np.ctypeslib.as_array(C.cast(send, C.POINTER(_d)), shape=(int(count),))
+            b = np.ctypeslib.as_array(C.cast(recv, C.POINTER(_d)), shape=(nranks, int(count)))
+            allgather(a, b)
+            return 0
+        except Exception as e:
+            print(f"host transport allgather failed: {e!r}", flush=True)
+            return 1
+
+    t = HostTransport(None, _EXCHANGE_CB(_exchange), _ALLGATHER_CB(_allgather))
+    _host_transport_keepalive.append(t)
+    if lib().mg_comm_init_host(rank, nranks, C.byref(t)) != 0:
+        _check()
+        raise MGError("mg_comm_init_host failed")
     _check()
 
 

@@ -8,9 +8,16 @@
 // (rows are contiguous in the row-major layout), and because the smoother is temporally
 // blocked ONE exchange of S+2 ghost rows feeds S sweeps + residual + restriction -- the
 // message count per V-cycle level is 2, not one per sweep.
+//
+// A second, host-staged transport (mg_comm_init_host) carries the SAME calls of the slab driver
+// over two callbacks of the embedding program (an MPI or gloo wire): it exists so that the real
+// rank-mode driver -- counts, peers, grouping, the collapse all-gather -- can be run by several
+// processes on ONE GPU box and compared with the oracle, which RCCL (one rank per device) cannot
+// do there.  It moves ghost rows only; all arithmetic stays on the device.
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <vector>
 
 #include "mg_internal.h"
 
@@ -19,6 +26,50 @@ namespace mg {
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_nranks = 1;
+
+// host-staged transport
+mg_host_transport g_host = {};
+bool g_host_on = false;
+int g_group_depth = 0;
+struct HostOp {
+    int is_send, peer;
+    double *dev;
+    size_t count;
+};
+std::vector<HostOp> g_ops;
+
+// run the queued point-to-point operations of one group: device -> host for the sends, the
+// embedding program's exchange (returns when every transfer has completed), host -> device
+void host_flush()
+{
+    if (g_ops.empty()) return;
+    Context &c = ctx();
+    (void)hipStreamSynchronize(c.stream);  // the rows being sent were written by kernels on this stream
+    const size_t n = g_ops.size();
+    std::vector<std::vector<double>> stage(n);
+    std::vector<int> is_send(n), peer(n);
+    std::vector<void *> bufs(n);  // handed over as void *const *
+    std::vector<size_t> counts(n);
+    for (size_t i = 0; i < n; ++i) {
+        const HostOp &o = g_ops[i];
+        stage[i].resize(o.count);
+        if (o.is_send && !MG_HIP(hipMemcpy(stage[i].data(), o.dev, o.count * sizeof(double), hipMemcpyDeviceToHost))) return;
+        is_send[i] = o.is_send;
+        peer[i] = o.peer;
+        bufs[i] = stage[i].data();
+        counts[i] = o.count;
+    }
+    if (g_host.exchange(g_host.user, (int)n, is_send.data(), peer.data(), bufs.data(), counts.data()) != 0) {
+        fail(MG_ERR_COMM, "host transport: exchange callback failed");
+        g_ops.clear();
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const HostOp &o = g_ops[i];
+        if (!o.is_send && !MG_HIP(hipMemcpy(o.dev, stage[i].data(), o.count * sizeof(double), hipMemcpyHostToDevice))) break;
+    }
+    g_ops.clear();
+}
 
 bool nccl_ok(ncclResult_t r, const char *what)
 {
@@ -29,29 +80,63 @@ bool nccl_ok(ncclResult_t r, const char *what)
 #define MG_NCCL(expr) nccl_ok((expr), #expr)
 }  // namespace
 
-bool comm_ready() { return g_comm != nullptr; }
+bool comm_ready() { return g_comm != nullptr || g_host_on; }
 int comm_rank() { return g_rank; }
 int comm_size() { return g_nranks; }
 
 // my rows [send_lo, send_lo+n) go to `peer`; rows from `peer` land at recv.  Either side may
 // be empty (n == 0).  All exchanges of one step are issued inside ONE group.
-void comm_group_begin() { MG_NCCL(ncclGroupStart()); }
-void comm_group_end() { MG_NCCL(ncclGroupEnd()); }
+void comm_group_begin()
+{
+    if (g_host_on) {
+        ++g_group_depth;
+        return;
+    }
+    MG_NCCL(ncclGroupStart());
+}
+void comm_group_end()
+{
+    if (g_host_on) {
+        if (--g_group_depth == 0) host_flush();
+        return;
+    }
+    MG_NCCL(ncclGroupEnd());
+}
 
 void comm_send(const double *buf, size_t count, int peer)
 {
-    if (count) MG_NCCL(ncclSend(buf, count, ncclDouble, peer, g_comm, ctx().stream));
+    if (!count) return;
+    if (g_host_on) {
+        g_ops.push_back(HostOp{1, peer, const_cast<double *>(buf), count});
+        if (g_group_depth == 0) host_flush();
+        return;
+    }
+    MG_NCCL(ncclSend(buf, count, ncclDouble, peer, g_comm, ctx().stream));
 }
 void comm_recv(double *buf, size_t count, int peer)
 {
-    if (count) MG_NCCL(ncclRecv(buf, count, ncclDouble, peer, g_comm, ctx().stream));
-}
-void comm_bcast(double *buf, size_t count, int root)
-{
-    MG_NCCL(ncclBroadcast(buf, buf, count, ncclDouble, root, g_comm, ctx().stream));
+    if (!count) return;
+    if (g_host_on) {
+        g_ops.push_back(HostOp{0, peer, buf, count});
+        if (g_group_depth == 0) host_flush();
+        return;
+    }
+    MG_NCCL(ncclRecv(buf, count, ncclDouble, peer, g_comm, ctx().stream));
 }
 void comm_allgather(const double *send, double *recv, size_t count_per_rank)
 {
+    if (g_host_on) {
+        Context &c = ctx();
+        (void)hipStreamSynchronize(c.stream);
+        std::vector<double> in(count_per_rank), out(count_per_rank * (size_t)g_nranks);
+        if (!MG_HIP(hipMemcpy(in.data(), send, in.size() * sizeof(double), hipMemcpyDeviceToHost))) return;
+        if (g_host.allgather(g_host.user, in.data(), out.data(), count_per_rank) != 0) {
+            fail(MG_ERR_COMM, "host transport: allgather callback failed");
+            return;
+        }
+        (void)MG_HIP(hipMemcpy(recv, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
+        return;
+    }
     MG_NCCL(ncclAllGather(send, recv, count_per_rank, ncclDouble, g_comm, ctx().stream));
 }
 
@@ -88,8 +173,29 @@ int mg_comm_init(int rank, int nranks, const void *unique_id)
     return 0;
 }
 
+// host-staged transport (see the head of this file); the callbacks must stay valid until
+// mg_comm_finalize
+int mg_comm_init_host(int rank, int nranks, const mg_host_transport *t)
+{
+    if (!require_ready("mg_comm_init_host")) return 1;
+    if (g_comm || g_host_on) return 0;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !t || !t->exchange || !t->allgather) {
+        fail(MG_ERR_ARG, "mg_comm_init_host: rank %d of %d, or a callback is missing", rank, nranks);
+        return 1;
+    }
+    g_host = *t;
+    g_host_on = true;
+    g_group_depth = 0;
+    g_ops.clear();
+    g_rank = rank;
+    g_nranks = nranks;
+    return 0;
+}
+
 void mg_comm_finalize(void)
 {
+    g_host_on = false;
+    g_ops.clear();
     if (g_comm) {
         (void)hipStreamSynchronize(ctx().stream);
         (void)ncclCommDestroy(g_comm);

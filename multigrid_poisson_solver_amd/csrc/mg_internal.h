@@ -160,7 +160,6 @@ void comm_group_begin();
 void comm_group_end();
 void comm_send(const double *buf, size_t count, int peer);
 void comm_recv(double *buf, size_t count, int peer);
-void comm_bcast(double *buf, size_t count, int root);
 void comm_allgather(const double *send, double *recv, size_t count_per_rank);
 
 // small host helper: run fn(begin,end) over [0,n) on the host threads

@@ -2,6 +2,8 @@
 slabs live in this process and exchange ghost rows by device copies (mg_slab_load rank=-1).
 The same driver code runs one rank per process over RCCL under bench.py --gpus N; only the
 transport (mg_comm.cpp) differs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,33 @@ def test_rccl_communicator_single_rank(mg):
     mg.comm_init(0, 1, uid)
     assert mg.lib().mg_comm_rank() == 0 and mg.lib().mg_comm_size() == 1
     mg.lib().mg_comm_finalize()
+
+
+@pytest.mark.parametrize("world,N,collapse", [(2, 512, 64), (3, 1024, 128), (4, 1024, 256)])
+def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse):
+    """The driver in RANK mode (one process per slab, as under RCCL) with the host-staged
+    transport over gloo: `world` processes on this one GPU, every rank's owned rows bit-identical
+    to the oracle's cycle, errors combined over ranks (tests/_slab_host_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path)
+    assert want["status"] == 0
+    want_path = str(tmp_path / "want.npz")
+    np.savez(want_path, N=N, U=want["U"], mg_error=want["mg_error"],
+             rec_nodes=np.array([(r[0], r[1]) for r in want["records"]]),
+             rec_errors=np.array([r[3] for r in want["records"]]))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(here, "_slab_host_worker.py"), path, want_path, str(collapse)]
+    out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert f"SLAB_HOST_TRANSPORT OK {world} {N} {collapse}" in out.stdout
