@@ -27,17 +27,43 @@ def grid_for(world, base=8192):
     return int(round(n / 64.0)) * 64
 
 
+def host_transport(mg, rank, world):
+    """Rehearsal wire (MG_BENCH_TRANSPORT=host): ghost rows staged through the host and carried by
+    gloo, so that several ranks can share the one GPU of a test box.  Never the measured path."""
+    def exchange(ops):
+        p2p = [dist.P2POp(dist.isend if is_send else dist.irecv, torch.from_numpy(buf), peer) for is_send, peer, buf in ops]
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+
+    def allgather(send, recv):
+        parts = [torch.empty(send.size, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(send.copy()))
+        for r in range(world):
+            recv[r, :] = parts[r].numpy()
+
+    mg.comm_init_host(rank, world, exchange, allgather)
+
+
 def run(args, rank, world, local_rank):
+    rehearsal = os.environ.get("MG_BENCH_TRANSPORT", "rccl") == "host"
+    if rehearsal:
+        local_rank = 0  # every rank on the one GPU
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if rehearsal:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import multigrid_poisson_solver_amd as mg
     from bench import level_sizes, vcycle_algorithmic_bytes
 
     mg.init(local_rank)
     mg.set_smoother("stream")
-    uid = [mg.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    mg.comm_init(rank, world, uid[0])
+    if rehearsal:
+        host_transport(mg, rank, world)
+    else:
+        uid = [mg.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        mg.comm_init(rank, world, uid[0])
 
     N = grid_for(world, args.n) if args.n == 8192 else args.n
     nu = args.nu
@@ -71,7 +97,7 @@ def run(args, rank, world, local_rank):
     assert r["status"] == 0, r
     plan.want_error(True)
     r = plan.execute()  # untimed: the result's error against the analytic solution
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -100,6 +126,8 @@ def run(args, rank, world, local_rank):
             "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
             "mg_error": r["mg_error"],
             "roofline": roof, "kernels": kernels[:6],
+            **({"transport": "host-staged over gloo, all ranks on ONE GPU: a plumbing rehearsal, not a measurement"}
+               if rehearsal else {}),
             "cycle_roofline": {"algorithmic_bytes": algo_bytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world,
                                "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 4)},
         }

@@ -6,7 +6,8 @@
 // away (ds_bpermute).  The residual norm needs the neighbours of the state after the black
 // pass -- exactly what the red pass of the NEXT iteration needs, so each iteration fetches
 // neighbours twice, not three times.  The norm is a DPP row scan + 4 readlanes; convergence is
-// tested every iteration like the reference's `while (err > target_error)` (:996).
+// tested every iteration like the reference's `while (err > target_error)` (:996), with the next
+// sweep issued speculatively beside the norm (see solve()).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -44,13 +45,28 @@ __device__ __forceinline__ double read_lane(double v, int lane)
     r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
     return r.d;
 }
+// CTRL: 0x142 = row_bcast:15 (lane 15 of each row -> the next row), 0x143 = row_bcast:31; lanes
+// outside ROW_MASK keep `v`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double row_bcast_add(double v)
+{
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xf, false);
+    return r.d;
+}
 __device__ __forceinline__ double wave_total(double v)
 {
     v += row_shr_zero<1>(v);
     v += row_shr_zero<2>(v);
     v += row_shr_zero<4>(v);
     v += row_shr_zero<8>(v);  // lanes 15, 31, 47, 63 hold their row's total
-    return ((read_lane(v, 15) + read_lane(v, 31)) + read_lane(v, 47)) + read_lane(v, 63);
+    // rows 1 and 3 add the total of the row below them, then rows 2-3 add lane 31's (= rows 0+1):
+    // lane 63 = (r0 + r1) + (r2 + r3).  Lanes outside the row mask add 0.
+    v += row_bcast_add<0x142, 0xa>(v);
+    v += row_bcast_add<0x143, 0xc>(v);
+    return read_lane(v, 63);
 }
 
 __device__ __forceinline__ float lane_shift(float v, int dpp_ctrl_is_shr)
@@ -89,12 +105,18 @@ __device__ __forceinline__ T solve(int N, T h2, T inv, T f, double tol, int max_
     const T h2f = h2 * f;
     const int l_s = lane >= N ? lane - N : 0, l_n = lane + N < 64 ? lane + N : 63;
     const double denom = (double)((N - 2) * (N - 2));
-    T u = 0.0;  // memset(U, 0)  :993
-    Neighbours<T> nb = fetch(u, l_n, l_s);
-    int iterations = 0;
-    for (;;) {
-        // red: U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F)  :1020
-        {
+    // `sum/denom > tol` decided without the division wherever rounding cannot matter (the fp64
+    // division is a dozen instructions of a loop that is bound by its instruction count)
+    const double thr = tol * denom, thr_hi = thr * (1.0 + 0x1p-48), thr_lo = thr * (1.0 - 0x1p-48);
+    auto above_tol = [&](double sum) {
+        if (sum > thr_hi) return true;
+        if (sum < thr_lo) return false;
+        return sum / denom > tol;  // :1059, :996
+    };
+    // One sweep = red pass, fetch, black pass, fetch (the second fetch serves the norm of this
+    // iterate AND the red pass of the next one).
+    auto sweep = [&](T &u, Neighbours<T> &nb) {
+        {   // red: U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F)  :1020
             const T nu = T(0.25) * (nb.w + nb.e + nb.n + nb.s - h2f);
             if (inside && colour == 0) u = nu;
         }
@@ -103,12 +125,26 @@ __device__ __forceinline__ T solve(int N, T h2, T inv, T f, double tol, int max_
             const T nu = T(0.25) * (nb.w + nb.e + nb.n + nb.s - h2f);
             if (inside && colour == 1) u = nu;
         }
-        ++iterations;
-        nb = fetch(u, l_n, l_s);  // serves the norm now and the next red pass
+        nb = fetch(u, l_n, l_s);
+    };
+    T u = 0.0;  // memset(U, 0)  :993
+    Neighbours<T> nb = fetch(u, l_n, l_s);
+    sweep(u, nb);
+    int iterations = 1;
+    // The reference tests `err > target` after every sweep (:996).  The norm of iterate i (a
+    // residual + a 64-lane reduction, ~40 % of a sweep's dependent chain) does not feed sweep
+    // i+1, so both are issued together and sweep i+1 is simply dropped when iterate i turns out
+    // to have converged: same iterates, same stopping iteration, shorter critical path.
+    for (;;) {
+        T un = u;
+        Neighbours<T> nbn = nb;
+        sweep(un, nbn);                                                                        // speculative
         const T rs = inv * (nb.n + nb.s + nb.e + nb.w - 4 * u) - f;  // :560
         const double res = inside ? fabs((double)rs) : 0.0;
-        const double err = wave_total(res) / denom;                                             // :1059
-        if (!(err > tol) || iterations >= max_iter) break;
+        if (!above_tol(wave_total(res)) || iterations >= max_iter) break;
+        u = un;
+        nb = nbn;
+        ++iterations;
     }
     *iterations_out = iterations;
     return u;
