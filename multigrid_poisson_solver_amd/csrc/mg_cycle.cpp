@@ -426,9 +426,28 @@ bool try_tail(Exec &x)
     a.U_top = top->U;
     a.err_dev = p->err_dev;
     a.gs_state = x.c.gs_state;
+    // diagnostics: MG_TAIL_TRACE=1 prints the in-kernel timeline of the first traced launches
+    static const bool trace_on = getenv("MG_TAIL_TRACE") != nullptr;
+    static int traced = 0;
+    long long *trace = nullptr;
+    if (trace_on && traced < 3 && !x.capturing) {
+        (void)hipMalloc((void **)&trace, (k::TAIL_MAX_NODES + 2) * sizeof(long long));
+        a.trace = trace;
+    }
     {
         ProfScope ps("coarse_tail", top->N, 0.0);
         k::tail_launch(x.c.stream, a);
+    }
+    if (trace) {
+        std::vector<long long> t((size_t)a.n_nodes + 2);
+        (void)hipStreamSynchronize(x.c.stream);
+        (void)hipMemcpy(t.data(), trace, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(trace);
+        ++traced;
+        fprintf(stderr, "[tail trace] staging %.2f us;", (double)(t[1] - t[0]) * 0.01);
+        for (int i = 0; i < a.n_nodes; ++i)
+            fprintf(stderr, " %d@%d:%.2f", a.nodes[i].type, a.N[node_level[i]], (double)(t[(size_t)i + 2] - t[(size_t)i + 1]) * 0.01);
+        fprintf(stderr, " us\n");
     }
     x.tok = tok;
     return true;

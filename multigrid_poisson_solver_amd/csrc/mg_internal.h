@@ -242,6 +242,8 @@ struct TailArgsT {
     const int *p_orow[TAIL_MAX_LEVELS], *p_ocol[TAIL_MAX_LEVELS];  // prolongation level l+1 -> l
     const T *p_rhi[TAIL_MAX_LEVELS], *p_rlo[TAIL_MAX_LEVELS], *p_chi[TAIL_MAX_LEVELS], *p_clo[TAIL_MAX_LEVELS];
     T c_dx[TAIL_MAX_LEVELS];
+    int tab_real0, tab_int0;  // where the staged tables start in LDS (set by the launcher)
+    long long *trace;         // diagnostics (MG_TAIL_TRACE): 100 MHz timestamps at start, after staging, after each node
     const T *F_top;
     T *U_top;
     double *err_dev;   // norms are fp64 whatever the field type

@@ -46,6 +46,7 @@
 
 #include <cstdlib>
 
+#include "mg_divconst.h"
 #include "mg_internal.h"
 
 #if !defined(MG_REAL) || !defined(MG_REAL_NS)
@@ -137,28 +138,7 @@ __device__ __forceinline__ float from_lane_above(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
-// x / c for a constant c whose correctly rounded reciprocal rc = RN(1/c) was formed on the
-// host.  q0 = RN(x*rc) is within 2 ulp of x/c; one residual correction makes it faithful and,
-// by Markstein's theorem (r = x - c*q exact through the FMA, rc correctly rounded), a second
-// one yields RN(x/c): the same bits as the IEEE division the reference performs in
-// doProlongation (src/MG_solver_CPU.cpp:700 ".../c_dx/c_dx"), in 5 instructions instead of
-// the ~14 of the hardware division sequence.  Inputs here are ordinary finite numbers.
-__device__ __forceinline__ double div_by_const(double x, double c, double rc)
-{
-    double q = x * rc;
-    double r = __builtin_fma(-q, c, x);
-    q = __builtin_fma(r, rc, q);
-    r = __builtin_fma(-q, c, x);
-    return __builtin_fma(r, rc, q);
-}
-__device__ __forceinline__ float div_by_const(float x, float c, float rc)
-{
-    float q = x * rc;
-    float r = __builtin_fmaf(-q, c, x);
-    q = __builtin_fmaf(r, rc, q);
-    r = __builtin_fmaf(-q, c, x);
-    return __builtin_fmaf(r, rc, q);
-}
+// x / c for a constant c: div_by_const(x, c, RN(1/c)), see mg_divconst.h
 
 // Read-only host-built tables are read through the constant address space: the compiler may
 // then use scalar loads (s_load, SGPR result, lgkmcnt) for wave-uniform indices instead of

@@ -9,10 +9,20 @@
 // the CU.  Every expression is the one the per-operator kernels use (reference order,
 // -ffp-contract=off), so the result is bit-identical to running the nodes one by one.
 //
+// One CU issues 64 lane-instructions per clock, so the kernel is bound by its instruction count,
+// not by LDS or HBM: a thread therefore owns FIXED points of a level (flat index, up to 4 at
+// N = 64) and keeps their U, F and h^2*F in registers across the sweeps of a node (4 LDS reads and
+// 1 write per point and sweep), the first sweep of a `-1` node starts from the zero field without
+// touching LDS, the residual is formed once per point (error norm and restriction share it), the
+// transfer tables are staged in LDS once per launch, `/c_dx/c_dx` is the correctly rounded
+// division by a constant of the streaming kernel, and the norm's last stage is left to thread 0
+// while the other waves go on.
+//
 // Kernel source for both field types (MG_REAL = double: mg_tail.hip; float: mg_tail_f32.hip, the
 // mixed-precision mode); with MG_REAL = double every expression is what it was before the split.
 #include <hip/hip_runtime.h>
 
+#include "mg_divconst.h"
 #include "mg_gs_wave.h"
 #include "mg_internal.h"
 
@@ -66,40 +76,73 @@ extern __shared__ __align__(16) real_t lds[];
 #define SRC(i) lds[src + (i)]
 #define FF(i) lds[F + (i)]
 
-// one Jacobi sweep src -> dst (src/MG_solver_CPU.cpp:587-599), rim keeps its value
-__device__ void sweep(int N, real_t dx2, int src, int F, int dst)
+// ---------------------------------------------------------------------------------------------
+// flat point ownership: thread t owns points t, t + 1024, ... of the level being worked on
+constexpr int PT = (TAIL_MAX_N * TAIL_MAX_N + TAIL_THREADS - 1) / TAIL_THREADS;
+
+struct Points {
+    int p[PT], r[PT], c[PT];
+    bool live[PT], inner[PT], even[PT];
+};
+__device__ __forceinline__ Points map_points(int N)
 {
-    FOR_POINTS(N, r, c, p)
-    {
-        real_t v = SRC(p);
-        if (!rim(r, c, N)) v = v + real_t(0.25) * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * SRC(p) - dx2 * FF(p));
-        lds[dst + p] = v;
+    Points P;
+    // row = floor(p / N) through one fp32 multiplication: (p + 0.5)/N is at least 0.5/N away from
+    // every integer, orders of magnitude more than the rounding error at p < 4096
+    const float rn = 1.0f / (float)N;
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int p = (int)threadIdx.x + k * TAIL_THREADS;
+        const int r = (int)(((float)p + 0.5f) * rn), c = p - r * N;
+        P.p[k] = p;
+        P.r[k] = r;
+        P.c[k] = c;
+        P.live[k] = p < N * N;
+        P.inner[k] = P.live[k] && r > 0 && c > 0 && r < N - 1 && c < N - 1;
+        P.even[k] = ((r + c) & 1) == 0;
+    }
+    return P;
+}
+
+// one Jacobi sweep src -> dst (src/MG_solver_CPU.cpp:587-599); v = this thread's own points of
+// src (kept in registers), rim keeps its value.  ZERO: src is the zero field (:256), nothing is read.
+template <bool ZERO>
+__device__ __forceinline__ void sweep(const Points &P, int N, int src, int dst, real_t (&v)[PT], const real_t (&h2f)[PT])
+{
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        if (!P.live[k]) continue;
+        const int p = P.p[k];
+        real_t nv = v[k];
+        if (P.inner[k]) {
+            if (ZERO) {
+                const real_t z = 0.0;
+                nv = z + real_t(0.25) * (z + z + z + z - 4 * z - h2f[k]);
+            } else {
+                nv = v[k] + real_t(0.25) * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * v[k] - h2f[k]);
+            }
+        }
+        lds[dst + p] = nv;
+        v[k] = nv;
     }
     __syncthreads();
 }
 
-// doSmoothing's error (:607-622)
-__device__ double smoothing_error(int N, real_t inv, int src, int F, double *sm)
+// first stage of doSmoothing's error (:607-622): this wave's sum into its slot
+__device__ __forceinline__ void post_partial(double acc, double *slots)
 {
-    double acc = 0.0;
-    FOR_POINTS(N, r, c, p)
-    {
-        if (!rim(r, c, N) && ((r + c) & 1) == 0)
-            acc += fabs((double)(inv * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * SRC(p)) - FF(p)));
-    }
-    const double s = block_total(acc, sm);
+    const double t = gsw::wave_total(acc);  // all 64 lanes are here
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = t;
+}
+// last stage, thread 0 only, after a barrier: fixed-order sum, (sum1 + sum2)/N/N  (:621-622)
+__device__ __forceinline__ void finish_error(const double *slots, int N, double *out)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < TAIL_WAVES; ++i) s += slots[i];
     double e = s + s;
     e = e / N / N;
-    return e;
-}
-
-// signed residual at one fine point: -(getResidual) as the driver forms it (:268, :277-280)
-__device__ __forceinline__ real_t neg_residual(int N, real_t inv, int src, int F, int r, int c)
-{
-    const int q = r * N + c;
-    real_t v = 0.0;
-    if (!rim(r, c, N)) v = inv * (SRC(q + N) + SRC(q - N) + SRC(q + 1) + SRC(q - 1) - 4 * SRC(q)) - FF(q);
-    return -v;
+    *out = e;
 }
 
 // The exact solver always computes in fp64, also under fp32 fields (mixed-precision mode): its
@@ -184,6 +227,25 @@ __device__ __forceinline__ int level_base(const TailArgsT<real_t> &a, int l)
         if (k < l) o += 3 * a.N[k] * a.N[k];
     return o;
 }
+// transfer tables of level pair l (l <-> l+1) staged in LDS: reals  w[M] rhi[N] rlo[N] chi[N] clo[N]
+// from a.tab_real0 (in real_t units), ints  lo[M] orow[N] ocol[N]  from a.tab_int0 (in int units)
+__device__ __forceinline__ int real_tab(const TailArgsT<real_t> &a, int l)
+{
+    int o = a.tab_real0;
+#pragma unroll
+    for (int k = 0; k < TAIL_MAX_LEVELS - 1; ++k)
+        if (k < l) o += a.N[k + 1] + 4 * a.N[k];
+    return o;
+}
+__device__ __forceinline__ int int_tab(const TailArgsT<real_t> &a, int l)
+{
+    int o = a.tab_int0;
+#pragma unroll
+    for (int k = 0; k < TAIL_MAX_LEVELS - 1; ++k)
+        if (k < l) o += a.N[k + 1] + 2 * a.N[k];
+    return o;
+}
+#define ITAB(i) (reinterpret_cast<int *>(lds)[(i)])
 
 // first double past the level arrays (fp32 fields only: fp64 scratch of the exact solver)
 __host__ __device__ __forceinline__ int gs_scratch(const TailArgsT<real_t> &a)
@@ -195,52 +257,89 @@ __host__ __device__ __forceinline__ int gs_scratch(const TailArgsT<real_t> &a)
 
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a)
 {
-    __shared__ double sm[17];
+    __shared__ double sm[17];                 // block_total of the block Gauss-Seidel
+    __shared__ double slots[2][TAIL_WAVES];   // error partials, alternating between nodes
     unsigned swapped = 0;  // bit l: level l's U currently lives in its second buffer (same in every thread)
     auto U_of = [&](int l) { return level_base(a, l) + (((swapped >> l) & 1u) ? a.N[l] * a.N[l] : 0); };
     auto T_of = [&](int l) { return level_base(a, l) + (((swapped >> l) & 1u) ? 0 : a.N[l] * a.N[l]); };
     auto F_of = [&](int l) { return level_base(a, l) + 2 * a.N[l] * a.N[l]; };
+    if (a.trace && threadIdx.x == 0) a.trace[0] = wall_clock64();
     {
+        // stage the finest source and all transfer tables: one global round trip for the launch
         const int N0 = a.N[0], f0 = F_of(0);
-        FOR_POINTS(N0, r, c, p) lds[f0 + p] = a.F_top[p];
+        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) lds[f0 + p] = a.F_top[p];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int l = 0; l + 1 < a.n_levels; ++l) {
+            const int N = a.N[l], M = a.N[l + 1], rt = real_tab(a, l), it = int_tab(a, l);
+            for (int i = lane; i < N; i += 64) {
+                if (wave == 0 && i < M) lds[rt + i] = a.r_w[l][i];
+                if (wave == 1) lds[rt + M + i] = a.p_rhi[l][i];
+                if (wave == 2) lds[rt + M + N + i] = a.p_rlo[l][i];
+                if (wave == 3) lds[rt + M + 2 * N + i] = a.p_chi[l][i];
+                if (wave == 4) lds[rt + M + 3 * N + i] = a.p_clo[l][i];
+                if (wave == 5 && i < M) ITAB(it + i) = a.r_lo[l][i];
+                if (wave == 6) ITAB(it + M + i) = a.p_orow[l][i];
+                if (wave == 7) ITAB(it + M + N + i) = a.p_ocol[l][i];
+            }
+        }
     }
     __syncthreads();
+    if (a.trace && threadIdx.x == 0) a.trace[1] = wall_clock64();
 
-    int cur = 0;
+    int cur = 0, parity = 0;
     for (int i = 0; i < a.n_nodes; ++i) {
         const TailNode nd = a.nodes[i];
+        if (a.trace && threadIdx.x == 0 && i > 0) a.trace[1 + i] = wall_clock64();
         if (nd.type == -1) {
             // memset(U,0) :256, doSmoothing :259, getResidual :268, sign flip :277-280, doRestriction :287
             const int N = a.N[cur], F = F_of(cur);
-            {
-                const int u = U_of(cur);
-                FOR_POINTS(N, r, c, p) lds[u + p] = 0.0;
+            const Points P = map_points(N);
+            const real_t dx2 = a.dx2[cur], inv = a.inv[cur];
+            real_t v[PT], f[PT], h2f[PT];
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                f[k] = P.live[k] ? lds[F + P.p[k]] : real_t(0.0);
+                h2f[k] = dx2 * f[k];
+                v[k] = 0.0;
             }
-            __syncthreads();
-            for (int s = 0; s < nd.steps; ++s) {
-                sweep(N, a.dx2[cur], U_of(cur), F, T_of(cur));
+            sweep<true>(P, N, 0, U_of(cur), v, h2f);
+            for (int s = 1; s < nd.steps; ++s) {
+                sweep<false>(P, N, U_of(cur), T_of(cur), v, h2f);
                 swapped ^= 1u << cur;
             }
-            const int src = U_of(cur);
-            const double e = smoothing_error(N, a.inv[cur], src, F, sm);
-            if (threadIdx.x == 0 && nd.err_slot >= 0) a.err_dev[nd.err_slot] = e;
-            const int M = a.N[cur + 1], Fc = F_of(cur + 1);
-            const int *lo = a.r_lo[cur];
-            const real_t *w = a.r_w[cur];
-            const real_t inv = a.inv[cur];
-            FOR_POINTS(M, rc, cc, q)
-            {
-                real_t v = 0.0;
-                if (!rim(rc, cc, M)) {
-                    const real_t wa = w[cc], wb = real_t(1.0) - wa, wc = w[rc], wd = real_t(1.0) - wc;
-                    const int fr = lo[rc], fc = lo[cc];
-                    const real_t u0 = neg_residual(N, inv, src, F, fr, fc);
-                    const real_t u1 = neg_residual(N, inv, src, F, fr, fc + 1);
-                    const real_t u2 = neg_residual(N, inv, src, F, fr + 1, fc);
-                    const real_t u3 = neg_residual(N, inv, src, F, fr + 1, fc + 1);
-                    v = wb * wd * u0 + wa * wd * u1 + wc * wb * u2 + wa * wc * u3;  // :676
+            // residual once per point: the error norm (:607-622) and, negated, the restriction's input
+            const int src = U_of(cur), D = T_of(cur);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                if (!P.live[k]) continue;
+                const int p = P.p[k];
+                real_t d = 0.0;
+                if (P.inner[k]) {
+                    d = inv * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * v[k]) - f[k];
+                    if (P.even[k]) acc += fabs((double)d);
                 }
-                lds[Fc + q] = v;
+                lds[D + p] = -d;
+            }
+            post_partial(acc, slots[parity]);
+            __syncthreads();
+            if (threadIdx.x == 0 && nd.err_slot >= 0) finish_error(slots[parity], N, a.err_dev + nd.err_slot);
+            parity ^= 1;
+            const int M = a.N[cur + 1], Fc = F_of(cur + 1);
+            const int rt = real_tab(a, cur), it = int_tab(a, cur);
+            const Points Q = map_points(M);
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                if (!Q.live[k]) continue;
+                real_t vc = 0.0;
+                if (Q.inner[k]) {
+                    const int rc = Q.r[k], cc = Q.c[k];
+                    const real_t wa = lds[rt + cc], wb = real_t(1.0) - wa, wc = lds[rt + rc], wd = real_t(1.0) - wc;
+                    const int q = D + ITAB(it + rc) * N + ITAB(it + cc);
+                    const real_t u0 = lds[q], u1 = lds[q + 1], u2 = lds[q + N], u3 = lds[q + N + 1];
+                    vc = wb * wd * u0 + wa * wd * u1 + wc * wb * u2 + wa * wc * u3;  // :676
+                }
+                lds[Fc + Q.p[k]] = vc;
             }
             __syncthreads();
             ++cur;
@@ -251,37 +350,68 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             __syncthreads();
         } else {  // 1: doProlongation :354, doGridAddition :368, doSmoothing :416
             const int Nc = a.N[cur], fine = cur - 1, N = a.N[fine];
-            const int uc = U_of(cur), uf = U_of(fine), F = F_of(fine);
-            const int *orow = a.p_orow[fine], *ocol = a.p_ocol[fine];
-            const real_t *rhi = a.p_rhi[fine], *rlo = a.p_rlo[fine], *chi = a.p_chi[fine], *clo = a.p_clo[fine];
-            const real_t c_dx = a.c_dx[fine];
-            FOR_POINTS(N, kf, l, q)
+            const int uc = U_of(cur), F = F_of(fine);
+            const int rt = real_tab(a, fine) + Nc, it = int_tab(a, fine) + Nc;  // past w[M] / lo[M]
+            const real_t c_dx = a.c_dx[fine], c_rcp = real_t(1.0) / c_dx, dx2 = a.dx2[fine], inv = a.inv[fine];
+            const Points P = map_points(N);
+            real_t v[PT], f[PT], h2f[PT];
             {
-                const int ci = orow[kf], cj = ocol[l];
-                if (ci < 0 || cj < 0) continue;
-                const int p = uc + ci * Nc + cj;
-                const real_t c1 = lds[p], c2 = lds[p + 1], c3 = lds[p + Nc], c4 = lds[p + Nc + 1];
-                const real_t v = ((c1 * chi[l] + c2 * clo[l]) * rhi[kf] + (c3 * chi[l] + c4 * clo[l]) * rlo[kf]) / c_dx / c_dx;
-                lds[uf + q] = lds[uf + q] + v;
+                const int uf = U_of(fine);
+#pragma unroll
+                for (int k = 0; k < PT; ++k) {
+                    f[k] = real_t(0.0);
+                    v[k] = real_t(0.0);
+                    if (P.live[k]) {
+                        const int q = P.p[k], kf = P.r[k], l = P.c[k];
+                        f[k] = lds[F + q];
+                        v[k] = lds[uf + q];
+                        const int ci = ITAB(it + kf), cj = ITAB(it + N + l);
+                        if (ci >= 0 && cj >= 0) {
+                            const int p = uc + ci * Nc + cj;
+                            const real_t c1 = lds[p], c2 = lds[p + 1], c3 = lds[p + Nc], c4 = lds[p + Nc + 1];
+                            const real_t rhi = lds[rt + kf], rlo = lds[rt + N + kf], chi = lds[rt + 2 * N + l], clo = lds[rt + 3 * N + l];
+                            const real_t num = (c1 * chi + c2 * clo) * rhi + (c3 * chi + c4 * clo) * rlo;
+                            v[k] = v[k] + div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);  // :700 .../c_dx/c_dx
+                            lds[uf + q] = v[k];
+                        }
+                    }
+                    h2f[k] = dx2 * f[k];
+                }
             }
             __syncthreads();
             for (int s = 0; s < nd.steps; ++s) {
-                sweep(N, a.dx2[fine], U_of(fine), F, T_of(fine));
+                sweep<false>(P, N, U_of(fine), T_of(fine), v, h2f);
                 swapped ^= 1u << fine;
             }
-            const double e = smoothing_error(N, a.inv[fine], U_of(fine), F, sm);
-            if (threadIdx.x == 0 && nd.err_slot >= 0) a.err_dev[nd.err_slot] = e;
+            const int src = U_of(fine);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                if (P.inner[k] && P.even[k]) {
+                    const int p = P.p[k];
+                    acc += fabs((double)(inv * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * v[k]) - f[k]));
+                }
+            }
+            post_partial(acc, slots[parity]);
+            __syncthreads();
+            if (threadIdx.x == 0 && nd.err_slot >= 0) finish_error(slots[parity], N, a.err_dev + nd.err_slot);
+            parity ^= 1;
             --cur;
         }
     }
+    if (a.trace && threadIdx.x == 0) a.trace[1 + a.n_nodes] = wall_clock64();
     {
         const int N0 = a.N[0], u0 = U_of(0);
-        FOR_POINTS(N0, r, c, p) a.U_top[p] = lds[u0 + p];
+        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) a.U_top[p] = lds[u0 + p];
     }
 }
 
-
-inline size_t tail_lds_bytes(const TailArgsT<real_t> &a)
+// LDS layout: level arrays | (fp32 fields) fp64 scratch of the block exact solver | real tables | int tables
+struct TailLayout {
+    int tab_real0, tab_int0;
+    size_t bytes;
+};
+inline TailLayout tail_layout(const TailArgsT<real_t> &a)
 {
     size_t bytes = 0;
     for (int l = 0; l < a.n_levels; ++l) bytes += (size_t)3 * a.N[l] * a.N[l] * sizeof(real_t);
@@ -295,8 +425,21 @@ inline size_t tail_lds_bytes(const TailArgsT<real_t> &a)
         }
         if (worst) bytes = (size_t)gs_scratch(a) * 8 + (size_t)2 * worst * worst * sizeof(double);
     }
-    return bytes;
+    bytes = (bytes + 7) / 8 * 8;
+    size_t n_real = 0, n_int = 0;
+    for (int l = 0; l + 1 < a.n_levels; ++l) {
+        n_real += (size_t)a.N[l + 1] + 4 * (size_t)a.N[l];
+        n_int += (size_t)a.N[l + 1] + 2 * (size_t)a.N[l];
+    }
+    TailLayout L;
+    L.tab_real0 = (int)(bytes / sizeof(real_t));
+    bytes += (n_real * sizeof(real_t) + 7) / 8 * 8;
+    L.tab_int0 = (int)(bytes / sizeof(int));
+    bytes += n_int * sizeof(int);
+    L.bytes = bytes;
+    return L;
 }
+inline size_t tail_lds_bytes(const TailArgsT<real_t> &a) { return tail_layout(a).bytes; }
 
 inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
 {
@@ -305,7 +448,11 @@ inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
         (void)hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(TAIL_THREADS), tail_lds_bytes(a), s, a);
+    const TailLayout L = tail_layout(a);
+    TailArgsT<real_t> b = a;
+    b.tab_real0 = L.tab_real0;
+    b.tab_int0 = L.tab_int0;
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(TAIL_THREADS), L.bytes, s, b);
 }
 
 }  // namespace MG_REAL_NS

@@ -12,10 +12,10 @@ sys.path.insert(0, ROOT)
 import multigrid_poisson_solver_amd as mg
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-reps = 20
+reps = 5 if os.environ.get("CYCLE") == "W" else 20
 mg.init(0)
 path = os.path.join(tempfile.mkdtemp(), "v.txt")
-mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+(mg.write_wcycle_file if os.environ.get("CYCLE") == "W" else mg.write_vcycle_file)(path, N, 8, 3, 1e-7)
 plan = mg.CyclePlan(path, fused=True, report=False, error=False, mixed=bool(os.environ.get("MIXED")))
 for _ in range(3):
     plan.execute()
