@@ -586,7 +586,8 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int resident = ctx().n_cu * blocks_per_cu;
     int chunks = resident / groups;
     // small grids are latency bound on the length of a wave's march: shorter chunks, more waves
-    const int min_rows = N <= 1024 ? 4 : 8;
+    static const int min_rows_forced = [] { const char *e = getenv("MG_MIN_ROWS"); return e ? atoi(e) : 0; }();
+    const int min_rows = min_rows_forced ? min_rows_forced : (N <= 256 ? 2 : N <= 1024 ? 4 : 8);
     const int max_chunks = (own + min_rows - 1) / min_rows;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
@@ -630,15 +631,10 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
 template <int S>
 void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
-    // rows in flight per lane: registers (occupancy) against prefetch depth.  MG_PF=2|4.
-    // Large grids fill the chip with waves: fewer registers (PF = 2) win.  Small grids are latency
-    // bound on one wave per SIMD: a deeper FIFO (PF = 4) covers the memory latency instead.
-    static const int forced = [] { const char *e = getenv("MG_PF"); return e ? atoi(e) : 0; }();
-    // (PF = 8 was tried for tiny grids and is slower: there a lone wave is bound by its own
-    // instruction stream, ~0.6 us per row, not by memory latency)
-    const int pf = forced ? forced : (p.N <= 2048 ? 4 : 2);
-    if (pf == 2) launch_variant<S, 2>(s, p, err_out);
-    else launch_variant<S, 4>(s, p, err_out);
+    // rows in flight per lane: PF = 2 (a FIFO of 4 slots).  A deeper FIFO (PF = 4, 8) costs registers
+    // and a longer prologue and measured slower at every size from 128 to 8192 once all loads were
+    // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).
+    launch_variant<S, 2>(s, p, err_out);
 }
 
 
