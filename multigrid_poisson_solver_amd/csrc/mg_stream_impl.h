@@ -583,7 +583,8 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT>::value;
     const int strips = (N + OW - 1) / OW;
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    const int resident = ctx().n_cu * blocks_per_cu;
+    static const int resident_pct = [] { const char *e = getenv("MG_RESIDENT_PCT"); return e ? atoi(e) : 100; }();
+    const int resident = ctx().n_cu * blocks_per_cu * resident_pct / 100;
     int chunks = resident / groups;
     // small grids are latency bound on the length of a wave's march: shorter chunks, more waves
     static const int min_rows_forced = [] { const char *e = getenv("MG_MIN_ROWS"); return e ? atoi(e) : 0; }();
