@@ -57,7 +57,8 @@ def measured_traffic(kernel_family):
     restrict = "true" if "restrict" in rest else "false"
     # the finest-level launch is the variant that moved the most bytes (the same template with
     # another prefetch depth serves the small levels)
-    hits = [v["total_bytes"] for name, v in data.items() if name.startswith(f"k_jacobi_stream<{steps}, 2, {mode}, {restrict}")]
+    hits = [v["total_bytes"] for name, v in data.items()
+            if name.split("::")[-1].startswith(f"k_jacobi_stream<{steps}, 2, {mode}, {restrict}") and not name.startswith("f32::")]
     return max(hits) if hits else None
 
 

@@ -275,7 +275,14 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         // odd count: dst alternates so that the last is U_out.  even count (own partner):
         // start in the partner, the last launch then lands in U_out as well.
         double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
-        if (stream) {
+        const bool plain_single = stream && take == 1 && src && !(i == 0 && fu.coarse) && !(last && (D_out || fu.Fc || error_dev)) &&
+                                  N >= 2048 && N % 2 == 0;
+        if (plain_single) {
+            // one bare sweep of a large grid: the one-row-per-block pair kernel is the faster of the two
+            // (5.1 vs 4.5 TB/s at N = 8192; same bits) -- there is nothing to fuse and no row history to amortise
+            ProfScope ps("jacobi_simple", N, (double)n * 24.0);
+            k::jacobi_simple(s, N, dx2, src, F, dst);
+        } else if (stream) {
             // algorithmic bytes: 24 B per sweep and point, + 8 for a folded
             // zero-fill, + 24 for a folded residual, + 8n + 8m for a folded restriction,
             // + 8m + 16n for a folded prolongation+addition; the fused error costs nothing

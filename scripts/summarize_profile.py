@@ -48,40 +48,55 @@ if stats:
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
     print()
 
-# per-kernel average duration split by grid size needs the trace itself
-trace = find("trace", "*kernel_trace.csv")
-dur = defaultdict(list)
-if trace:
-    for r in csv.DictReader(open(trace)):
-        key = (short(r["Kernel_Name"]), grid_of(r))
-        dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-
-
-def counter(sub, cname):
-    f = find(sub, "*counter_collection.csv")
+# Per-launch join of the three runs.  The program is deterministic, so the i-th dispatch of a
+# kernel name in the trace run is the i-th dispatch of that name in the two counter runs.  The grid
+# cannot tell the levels apart (one resident round of workgroups at every size), so the launches of
+# one kernel are clustered by the bytes they moved.
+def per_dispatch(path, value):
     acc = defaultdict(list)
-    if not f:
+    if not path:
         return acc
-    for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") != cname:
-            continue
-        key = (short(r["Kernel_Name"]), grid_of(r))
-        acc[key].append(float(r["Counter_Value"]))
+    rows = list(csv.DictReader(open(path)))
+    idk = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+    if idk:
+        rows.sort(key=lambda r: int(r[idk]))
+    for r in rows:
+        v = value(r)
+        if v is not None:
+            acc[short(r["Kernel_Name"])].append(v)
     return acc
 
 
-fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+dur = per_dispatch(find("trace", "*kernel_trace.csv"), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+fetch = per_dispatch(find("fetch", "*counter_collection.csv"),
+                     lambda r: float(r["Counter_Value"]) if r.get("Counter_Name") == "FETCH_SIZE" else None)
+write = per_dispatch(find("write", "*counter_collection.csv"),
+                     lambda r: float(r["Counter_Value"]) if r.get("Counter_Name") == "WRITE_SIZE" else None)
 if fetch or write:
-    print("## HBM traffic per launch (separate --pmc passes; FETCH_SIZE x2 on gfx950, KiB -> bytes)\n")
-    print("| kernel | grid | launches | avg us | read MB | write MB | total MB | GB/s |\n|---|---|---|---|---|---|---|---|")
-    keys = sorted(set(fetch) | set(write), key=lambda k: -sum(dur.get(k, [0])))
-    for k in keys[:14]:
-        rd = 2.0 * 1024 * sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [1])))
-        wr = 1024 * sum(write.get(k, [0])) / max(1, len(write.get(k, [1])))
-        d = dur.get(k, [])
-        avg = sum(d) / len(d) if d else 0.0
+    print("## HBM traffic per launch (separate --pmc passes joined per dispatch; FETCH_SIZE x2 on gfx950, KiB -> bytes)\n")
+    print("| kernel | launches | avg us | read MB | write MB | total MB | GB/s |\n|---|---|---|---|---|---|---|")
+    table = []
+    for name in set(fetch) | set(write):
+        d, f, w = dur.get(name, []), fetch.get(name, []), write.get(name, [])
+        n = min(len(d), len(f), len(w))
+        if n == 0:
+            continue
+        rows = sorted(((2.0 * 1024 * f[i], 1024 * w[i], d[i]) for i in range(n)), key=lambda t: -(t[0] + t[1]))
+        clusters, cur = [], [rows[0]]
+        for t in rows[1:]:
+            if (cur[-1][0] + cur[-1][1]) > 1.6 * (t[0] + t[1]) + 1e5:
+                clusters.append(cur)
+                cur = []
+            cur.append(t)
+        clusters.append(cur)
+        for c in clusters:
+            rd = sum(t[0] for t in c) / len(c)
+            wr = sum(t[1] for t in c) / len(c)
+            avg = sum(t[2] for t in c) / len(c)
+            table.append((avg * len(c), name, len(c), avg, rd, wr))
+    for _tot, name, n, avg, rd, wr in sorted(table, reverse=True)[:18]:
         gbs = (rd + wr) / (avg * 1e-6) / 1e9 if avg else 0.0
-        print(f"| {k[0]} | {k[1]} | {len(d)} | {avg:.1f} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} | {gbs:.0f} |")
+        print(f"| {name} | {n} | {avg:.1f} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} | {gbs:.0f} |")
 
 
 # ---- per-kernel HBM bytes of the LARGEST launches (the finest level), for bench.py's roofline.traffic
