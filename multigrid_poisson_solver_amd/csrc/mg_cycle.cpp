@@ -954,9 +954,19 @@ int mg_cycle_main(int argc, char **argv)
     printf("Cycle structure file name = %s\n", argv[2]);  // :63
     const char *dev = getenv("MG_DEVICE");
     if (mg_init(dev ? atoi(dev) : 0) != 0) return 1;
-    mg_cycle_plan *plan = mg_cycle_load(argv[2], MG_CYCLE_FUSED | MG_CYCLE_REPORT | MG_CYCLE_ERROR);
+    // MG_MIXED=1: the fp32 cycle (what the reference's MG_GPU program computes in);  MG_REFINE=k: k such
+    // cycles joined by an fp64 residual and correction.  Same report and CSV.
+    const char *mixed = getenv("MG_MIXED"), *refine = getenv("MG_REFINE");
+    const bool want_mixed = (mixed && atoi(mixed) != 0) || (refine && atoi(refine) > 1);
+    mg_cycle_plan *plan = mg_cycle_load(argv[2], MG_CYCLE_FUSED | MG_CYCLE_REPORT | MG_CYCLE_ERROR | (want_mixed ? MG_CYCLE_MIXED : 0));
     if (!plan) {
+        // (a failed call has already printed its reason to stderr and, by default, exited)
         printf("[ ERROR ]: Cannot open file %s\n", argv[2]);  // :66
+        return 1;
+    }
+    if (refine && atoi(refine) > 1 && mg_cycle_set_refinement(plan, atoi(refine)) != 0) {
+        printf("[ ERROR ]: %s\n", mg_last_error_string());
+        mg_cycle_destroy(plan);
         return 1;
     }
     mg_cycle_result res;

@@ -113,3 +113,23 @@ def test_refinement_keeps_reducing_the_fp64_residual(mg, tmp_path):
     assert e[-1] < 0.2 * e[0], e
     assert got["mg_error"] < single["mg_error"]
     plan.close()
+
+
+def test_command_line_program_mixed(mg, cycle_dir, tmp_path):
+    """MG_MIXED=1 / MG_REFINE=k on the reference's command line: same report layout and CSV format,
+    values within fp32 rounding of the fp64 run of the same file."""
+    import os
+    import shutil
+    import subprocess
+    shutil.copy(os.path.join(cycle_dir, "Vcycle.txt"), tmp_path)
+    runs = {}
+    for tag, env in (("f64", {}), ("mixed", {"MG_MIXED": "1"}), ("refine", {"MG_REFINE": "3"})):
+        out = subprocess.run([mg.EXE_PATH, "4", "Vcycle.txt"], cwd=tmp_path, capture_output=True, text=True,
+                             env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "Output file name = Sol_HIP_Vcycle.txt" in out.stdout and "===== Final Result =====" in out.stdout
+        runs[tag] = np.loadtxt(tmp_path / "Sol_HIP_Vcycle.txt", delimiter=",")
+    scale = np.abs(runs["f64"]).max()
+    assert runs["mixed"].shape == runs["f64"].shape
+    assert 0 < np.abs(runs["mixed"] - runs["f64"]).max() <= 2e-5 * scale
+    assert np.abs(runs["refine"] - runs["f64"]).max() <= 0.5 * scale   # another iterate, same problem
