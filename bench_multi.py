@@ -75,7 +75,7 @@ def run(args, rank, world, local_rank):
     algo_bytes = vcycle_algorithmic_bytes(sizes, nu, nu)
 
     collapse_N = int(os.environ.get("MG_COLLAPSE_N", "1024"))
-    plan = mg.SlabPlan(cyc, world, rank, collapse_N)
+    plan = mg.SlabPlan(cyc, world, rank, collapse_N, mixed=args.mixed)
     for _ in range(max(1, args.warmup)):
         r = plan.execute()
         assert r["status"] == 0, r
@@ -119,9 +119,9 @@ def run(args, rank, world, local_rank):
         out = {
             "metric": "vcycle_mlups", "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"V({nu},{nu})-cycle N={N}^2 fp64 ({N * N // world} points per GPU), {len(sizes)} levels, "
-                                   f"{world} row slabs, ghost rows over RCCL, levels N<={collapse_N} on rank 0",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
+            "config": {"workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
+                                   f"{len(sizes)} levels, {world} row slabs, ghost rows over RCCL, levels N<={collapse_N} replicated on every rank",
                        "N": N, "levels": len(sizes), "parallelism": f"slab{world}"},
             "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
             "mg_error": r["mg_error"],

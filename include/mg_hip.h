@@ -229,13 +229,13 @@ int  mg_comm_init(int rank, int nranks, const void *unique_id);
 /* Host-staged transport instead of RCCL: the slab driver's ghost-row groups and its all-gather are
  * handed to two callbacks of the embedding program (MPI, gloo, ...) with HOST buffers.  `exchange`
  * receives the n_ops point-to-point operations of one group (is_send[i], peer[i], buf[i],
- * count[i] doubles) and returns 0 when ALL of them have completed; operations between two ranks
+ * bytes[i]) and returns 0 when ALL of them have completed; operations between two ranks
  * are posted in the same order on both sides.  `allgather` fills recv[r*count .. ] with rank r's
  * `send`.  Purpose: running the real rank-mode driver with several processes on one GPU (RCCL
  * allows one rank per device), and clusters without xGMI.  Arithmetic stays on the device. */
 typedef struct mg_host_transport {
     void *user;
-    int (*exchange)(void *user, int n_ops, const int *is_send, const int *peer, void *const *buf, const size_t *count);
+    int (*exchange)(void *user, int n_ops, const int *is_send, const int *peer, void *const *buf, const size_t *bytes);
     int (*allgather)(void *user, const double *send, double *recv, size_t count_per_rank);
 } mg_host_transport;
 int  mg_comm_init_host(int rank, int nranks, const mg_host_transport *transport);
@@ -255,6 +255,9 @@ typedef struct mg_slab_plan mg_slab_plan;
  * how the decomposition is verified bit for bit on one GPU).  Levels with N <= collapse_N
  * run on rank 0 only.  Supported grammar: con_N = 1, fixed con_step in 1..4, option 1. */
 mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N);
+/* the same with flags: MG_CYCLE_MIXED = the whole cycle on fp32 slabs (half the HBM and xGMI bytes;
+ * source rounded once, exact solver in fp64, mg_slab_gather_U widens), BASELINE.json configs[4] */
+mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int collapse_N, int flags);
 /* one run of the reference's timed window; U_dev is NULL (use mg_slab_gather_U) */
 int  mg_slab_execute(mg_slab_plan *plan, mg_cycle_result *out);
 /* like mg_cycle_enqueue / mg_cycle_collect */

@@ -80,7 +80,7 @@ ABI = {
     "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_rank": (_i, []),
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
-    "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
+    "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
     "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
@@ -533,13 +533,13 @@ _host_transport_keepalive = []
 
 def comm_init_host(rank, nranks, exchange, allgather):
     """mg_comm_init_host with Python callables:
-    exchange(ops) with ops = [(is_send, peer, float64 ndarray view of the host buffer), ...] must
+    exchange(ops) with ops = [(is_send, peer, uint8 ndarray view of the host buffer), ...] must
     complete every transfer before returning; allgather(send, recv) fills recv (nranks x count)."""
 
     def _exchange(_user, n, is_send, peer, buf, count):
         try:
             ops = [(bool(is_send[i]), int(peer[i]),
-                    np.ctypeslib.as_array(C.cast(buf[i], C.POINTER(_d)), shape=(int(count[i]),))) for i in range(n)]
+                    np.ctypeslib.as_array(C.cast(buf[i], C.POINTER(C.c_uint8)), shape=(int(count[i]),))) for i in range(n)]
             exchange(ops)
             return 0
         except Exception as e:  # never unwind through the C frame
@@ -576,8 +576,8 @@ def comm_unique_id():
 class SlabPlan:
     """The cycle-file driver on a 1-D row-slab decomposition (mg_slab_*)."""
 
-    def __init__(self, path, nranks, rank=-1, collapse_N=512):
-        self._plan = lib().mg_slab_load(os.fsencode(path), nranks, rank, collapse_N)
+    def __init__(self, path, nranks, rank=-1, collapse_N=512, mixed=False):
+        self._plan = lib().mg_slab_load_flags(os.fsencode(path), nranks, rank, collapse_N, MG_CYCLE_MIXED if mixed else 0)
         _check()
         if not self._plan:
             raise MGError(f"cannot load cycle file {path} in row-slab mode")

@@ -571,6 +571,45 @@ void slab_smooth(int N, double L, const double *U_in, double *U_out, const doubl
     k::jacobi_stream(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, nullptr, -1, sf.coarse, sf.Nc, pt, sf.Fc,
                      sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
 }
+
+void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const float *F, int step, double *raw_norm_out,
+                     const SlabFusion &sf)
+{
+    Context &c = ctx();
+    const double dx2 = spacing_sq(N, L);
+    if (step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N)) {
+        fail(MG_ERR_UNSUPPORTED, "row-slab mode: %d smoothing steps on N=%d (need 1..%d steps, even N)", step, N,
+             k::stream_max_steps());
+        return;
+    }
+    const ProlongTable *pt = nullptr;
+    const RestrictTable *rt = nullptr;
+    if (sf.coarse) {
+        pt = &prolong_table(sf.Nc, N);
+        if (!pt->owner_row || !pt->fusable) {
+            fail(MG_ERR_UNSUPPORTED, "row-slab mode: prolongation %d -> %d is not fusable", sf.Nc, N);
+            return;
+        }
+    }
+    if (sf.Fc) {
+        rt = &restrict_table(N, sf.M);
+        if (!rt->lo || !rt->fusable) {
+            fail(MG_ERR_UNSUPPORTED, "row-slab mode: restriction %d -> %d is not fusable", N, sf.M);
+            return;
+        }
+    }
+    const size_t n = (size_t)(sf.fine_w.own_hi - sf.fine_w.own_lo) * N;
+    double bytes = (double)n * (12.0 * step + (U_in ? 0.0 : 4.0) + (sf.Fc ? 12.0 : 0.0));
+    if (sf.Fc) bytes += 4.0 * n + 1.0 * n;
+    if (sf.coarse) bytes += 8.0 * n + 1.0 * n;
+    char name[48];
+    snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s>", step, U_in ? "" : ",zero", sf.coarse ? ",prolong" : "",
+             sf.Fc ? ",res,restrict" : "");
+    ProfScope ps(name, N, bytes);
+    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, (const float *)sf.coarse,
+                         sf.Nc, pt, (float *)sf.Fc, sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr,
+                         sf.Fc ? &sf.fc_w : nullptr);
+}
 }  // namespace mg
 
 extern "C" {

@@ -33,8 +33,8 @@ bool g_host_on = false;
 int g_group_depth = 0;
 struct HostOp {
     int is_send, peer;
-    double *dev;
-    size_t count;
+    void *dev;
+    size_t bytes;
 };
 std::vector<HostOp> g_ops;
 
@@ -46,18 +46,18 @@ void host_flush()
     Context &c = ctx();
     (void)hipStreamSynchronize(c.stream);  // the rows being sent were written by kernels on this stream
     const size_t n = g_ops.size();
-    std::vector<std::vector<double>> stage(n);
+    std::vector<std::vector<unsigned char>> stage(n);
     std::vector<int> is_send(n), peer(n);
     std::vector<void *> bufs(n);  // handed over as void *const *
     std::vector<size_t> counts(n);
     for (size_t i = 0; i < n; ++i) {
         const HostOp &o = g_ops[i];
-        stage[i].resize(o.count);
-        if (o.is_send && !MG_HIP(hipMemcpy(stage[i].data(), o.dev, o.count * sizeof(double), hipMemcpyDeviceToHost))) return;
+        stage[i].resize(o.bytes);
+        if (o.is_send && !MG_HIP(hipMemcpy(stage[i].data(), o.dev, o.bytes, hipMemcpyDeviceToHost))) return;
         is_send[i] = o.is_send;
         peer[i] = o.peer;
         bufs[i] = stage[i].data();
-        counts[i] = o.count;
+        counts[i] = o.bytes;
     }
     if (g_host.exchange(g_host.user, (int)n, is_send.data(), peer.data(), bufs.data(), counts.data()) != 0) {
         fail(MG_ERR_COMM, "host transport: exchange callback failed");
@@ -66,7 +66,7 @@ void host_flush()
     }
     for (size_t i = 0; i < n; ++i) {
         const HostOp &o = g_ops[i];
-        if (!o.is_send && !MG_HIP(hipMemcpy(o.dev, stage[i].data(), o.count * sizeof(double), hipMemcpyHostToDevice))) break;
+        if (!o.is_send && !MG_HIP(hipMemcpy(o.dev, stage[i].data(), o.bytes, hipMemcpyHostToDevice))) break;
     }
     g_ops.clear();
 }
@@ -103,25 +103,25 @@ void comm_group_end()
     MG_NCCL(ncclGroupEnd());
 }
 
-void comm_send(const double *buf, size_t count, int peer)
+void comm_send(const void *buf, size_t bytes, int peer)
 {
-    if (!count) return;
+    if (!bytes) return;
     if (g_host_on) {
-        g_ops.push_back(HostOp{1, peer, const_cast<double *>(buf), count});
+        g_ops.push_back(HostOp{1, peer, const_cast<void *>(buf), bytes});
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(ncclSend(buf, count, ncclDouble, peer, g_comm, ctx().stream));
+    MG_NCCL(ncclSend(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
 }
-void comm_recv(double *buf, size_t count, int peer)
+void comm_recv(void *buf, size_t bytes, int peer)
 {
-    if (!count) return;
+    if (!bytes) return;
     if (g_host_on) {
-        g_ops.push_back(HostOp{0, peer, buf, count});
+        g_ops.push_back(HostOp{0, peer, buf, bytes});
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(ncclRecv(buf, count, ncclDouble, peer, g_comm, ctx().stream));
+    MG_NCCL(ncclRecv(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
 }
 void comm_allgather(const double *send, double *recv, size_t count_per_rank)
 {

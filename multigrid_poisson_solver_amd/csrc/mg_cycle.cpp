@@ -160,6 +160,41 @@ namespace mg {
 // not including the `1` that leaves it, into a TailArgs (levels, spacings, transfer tables; the
 // caller fills F_top/U_top/err_dev/gs_state and the error slots).  node_level[i] = tail level
 // node i works on.  Returns false, consuming nothing, when the slice has another shape.
+// the same slice with fp32 fields: spacings and transfer weights rounded to fp32 (the exact solver
+// keeps its fp64 spacings); F_top / U_top / err_dev / gs_state are the caller's to set
+k::TailArgsF tail_args_f32(const k::TailArgs &a)
+{
+    k::TailArgsF f;
+    memset(&f, 0, sizeof f);
+    f.n_levels = a.n_levels;
+    f.n_nodes = a.n_nodes;
+    for (int i = 0; i < a.n_nodes; ++i) f.nodes[i] = a.nodes[i];
+    for (int l = 0; l < a.n_levels; ++l) {
+        f.N[l] = a.N[l];
+        f.dx2[l] = (float)a.dx2[l];
+        f.inv[l] = (float)a.inv[l];
+        f.gs_h2[l] = a.gs_h2[l];
+        f.gs_inv[l] = a.gs_inv[l];
+        if (l + 1 < a.n_levels) {
+            const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
+            const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
+            f.r_lo[l] = rt.lo;
+            f.r_w[l] = rt.w_f;
+            f.p_orow[l] = pt.owner_row;
+            f.p_ocol[l] = pt.owner_col;
+            f.p_rhi[l] = pt.row_hi_f;
+            f.p_rlo[l] = pt.row_lo_f;
+            f.p_chi[l] = pt.col_hi_f;
+            f.p_clo[l] = pt.col_lo_f;
+            f.c_dx[l] = (float)pt.c_dx;
+        }
+    }
+    f.err_dev = a.err_dev;
+    f.gs_state = a.gs_state;
+    f.trace = a.trace;
+    return f;
+}
+
 bool scan_tail(const std::vector<double> &tokens, size_t *tok_io, const std::vector<int> &sizes, int at0, int con_step,
                int top_N, double L, k::TailArgs *out, int *node_level)
 {
@@ -387,32 +422,7 @@ bool try_tail(Exec &x)
         }
     }
     if (p->flags & MG_CYCLE_MIXED) {
-        // the same slice with fp32 fields: spacings and transfer weights rounded to fp32
-        k::TailArgsF f;
-        memset(&f, 0, sizeof f);
-        f.n_levels = a.n_levels;
-        f.n_nodes = a.n_nodes;
-        for (int i = 0; i < a.n_nodes; ++i) f.nodes[i] = a.nodes[i];
-        for (int l = 0; l < a.n_levels; ++l) {
-            f.N[l] = a.N[l];
-            f.dx2[l] = (float)a.dx2[l];
-            f.inv[l] = (float)a.inv[l];
-            f.gs_h2[l] = a.dx2[l];
-            f.gs_inv[l] = a.inv[l];
-            if (l + 1 < a.n_levels) {
-                const RestrictTable &rt = restrict_table(a.N[l], a.N[l + 1]);
-                const ProlongTable &pt = prolong_table(a.N[l + 1], a.N[l]);
-                f.r_lo[l] = rt.lo;
-                f.r_w[l] = rt.w_f;
-                f.p_orow[l] = pt.owner_row;
-                f.p_ocol[l] = pt.owner_col;
-                f.p_rhi[l] = pt.row_hi_f;
-                f.p_rlo[l] = pt.row_lo_f;
-                f.p_chi[l] = pt.col_hi_f;
-                f.p_clo[l] = pt.col_lo_f;
-                f.c_dx[l] = (float)pt.c_dx;
-            }
-        }
+        k::TailArgsF f = tail_args_f32(a);
         f.F_top = (const float *)top->F;
         f.U_top = (float *)top->U;
         f.err_dev = p->err_dev;

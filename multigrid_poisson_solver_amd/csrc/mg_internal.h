@@ -151,6 +151,9 @@ struct SlabFusion {
 };
 void slab_smooth(int N, double L, const double *U_in, double *U_out, const double *F, int step, double *raw_norm_out,
                  const SlabFusion &sf);
+// the same launch on fp32 fields (mixed-precision slabs): the pointers inside sf are float arrays
+void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const float *F, int step, double *raw_norm_out,
+                     const SlabFusion &sf);
 
 // RCCL transport (mg_comm.cpp)
 bool comm_ready();
@@ -158,8 +161,8 @@ int comm_rank();
 int comm_size();
 void comm_group_begin();
 void comm_group_end();
-void comm_send(const double *buf, size_t count, int peer);
-void comm_recv(double *buf, size_t count, int peer);
+void comm_send(const void *buf, size_t bytes, int peer);   // byte counts: fp64 and fp32 slabs share the transport
+void comm_recv(void *buf, size_t bytes, int peer);
 void comm_allgather(const double *send, double *recv, size_t count_per_rank);
 
 // small host helper: run fn(begin,end) over [0,n) on the host threads
@@ -219,7 +222,8 @@ void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2
 // optional restriction output; whole grid local
 void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                        double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
-                       const RestrictTable *rt);
+                       const RestrictTable *rt, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
+                       const RowWindow *fc_w = nullptr);
 // coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
 constexpr int TAIL_MAX_LEVELS = 6;
 constexpr int TAIL_MAX_NODES = 48;
@@ -261,6 +265,8 @@ void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const 
 int  gs_single_workgroup_max_n();
 }  // namespace k
 
+// fp32 view of a coarse-tail slice: spacings and transfer weights rounded once (mg_cycle.cpp)
+k::TailArgsF tail_args_f32(const k::TailArgs &a);
 // collect the coarse-tail slice of a cycle file's node stream (mg_cycle.cpp)
 bool scan_tail(const std::vector<double> &tokens, size_t *tok_io, const std::vector<int> &sizes, int at0, int con_step,
                int top_N, double L, k::TailArgs *out, int *node_level);

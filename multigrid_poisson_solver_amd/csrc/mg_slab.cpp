@@ -118,6 +118,9 @@ struct mg_slab_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int status = 0;
     int want_error = 1;   // evaluate the analytic error after the window (outside the timing)
+    bool mixed = false;   // MG_CYCLE_MIXED: fp32 fields (the double* members then only carry addresses)
+    size_t elem = sizeof(double);
+    std::vector<double *> U64;   // mixed: per local rank, the finest window widened to fp64 (result / error)
 };
 
 namespace {
@@ -133,12 +136,17 @@ RowWindow window_of(const Partition &part, int r)
 }
 
 double *row_ptr(double *a, const RowWindow &w, int N, int y) { return a + (size_t)(y - w.base) * N; }
+// the same for a plan's arrays, whose element size depends on the mode
+void *row_at(const mg_slab_plan *p, double *a, const RowWindow &w, int N, int y)
+{
+    return (char *)a + (size_t)(y - w.base) * N * p->elem;
+}
 
 void alloc_level(mg_slab_plan *p, Level &lv)
 {
     lv.loc.resize(p->local.size());
     if (lv.collapsed) {
-        const size_t bytes = (size_t)lv.N * lv.N * sizeof(double);
+        const size_t bytes = (size_t)lv.N * lv.N * p->elem;
         for (Local &l : lv.loc) {
             l.U = (double *)p->pool.get(bytes);
             l.F = (double *)p->pool.get(bytes);
@@ -148,7 +156,7 @@ void alloc_level(mg_slab_plan *p, Level &lv)
     }
     for (size_t i = 0; i < p->local.size(); ++i) {
         const RowWindow w = window_of(lv.part, p->local[i]);
-        const size_t bytes = (size_t)w.rows * lv.N * sizeof(double);
+        const size_t bytes = (size_t)w.rows * lv.N * p->elem;
         lv.loc[i].U = (double *)p->pool.get(bytes);
         lv.loc[i].F = (double *)p->pool.get(bytes);
         lv.loc[i].D = (double *)p->pool.get(bytes);
@@ -182,17 +190,17 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items)
     for (const GhostItem &it : items) {
         Level &lv = *it.lv;
         const int N = lv.N;
-        const size_t cnt = (size_t)GHOST * N;
+        const size_t cnt = (size_t)GHOST * N * p->elem;  // bytes
         auto arr = [&](size_t i) { return it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F; };
         if (!p->real) {
             for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
                 const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
                 double *A = arr((size_t)r), *B = arr((size_t)r + 1);
                 // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
-                (void)hipMemcpyAsync(row_ptr(B, b, N, b.own_lo - GHOST), row_ptr(A, a, N, a.own_hi - GHOST),
-                                     cnt * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
-                (void)hipMemcpyAsync(row_ptr(A, a, N, a.own_hi), row_ptr(B, b, N, b.own_lo), cnt * sizeof(double),
+                (void)hipMemcpyAsync(row_at(p, B, b, N, b.own_lo - GHOST), row_at(p, A, a, N, a.own_hi - GHOST), cnt,
                                      hipMemcpyDeviceToDevice, c.stream);
+                (void)hipMemcpyAsync(row_at(p, A, a, N, a.own_hi), row_at(p, B, b, N, b.own_lo), cnt, hipMemcpyDeviceToDevice,
+                                     c.stream);
             }
             continue;
         }
@@ -200,12 +208,12 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items)
         const RowWindow w = window_of(lv.part, r);
         double *A = arr(0);
         if (r + 1 < R) {
-            comm_send(row_ptr(A, w, N, w.own_hi - GHOST), cnt, r + 1);
-            comm_recv(row_ptr(A, w, N, w.own_hi), cnt, r + 1);
+            comm_send(row_at(p, A, w, N, w.own_hi - GHOST), cnt, r + 1);
+            comm_recv(row_at(p, A, w, N, w.own_hi), cnt, r + 1);
         }
         if (r > 0) {
-            comm_send(row_ptr(A, w, N, w.own_lo), cnt, r - 1);
-            comm_recv(row_ptr(A, w, N, w.own_lo - GHOST), cnt, r - 1);
+            comm_send(row_at(p, A, w, N, w.own_lo), cnt, r - 1);
+            comm_recv(row_at(p, A, w, N, w.own_lo - GHOST), cnt, r - 1);
         }
     }
     if (p->real) comm_group_end();
@@ -219,18 +227,18 @@ void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart)
     Context &c = ctx();
     const int M = coarse.N, R = p->nranks;
     if (R == 1) return;
-    auto off = [&](int r) { return (size_t)cpart.lo[(size_t)r] * M; };
-    auto cnt = [&](int r) { return (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M; };
+    auto off = [&](int r) { return (size_t)cpart.lo[(size_t)r] * M * p->elem; };                            // bytes
+    auto cnt = [&](int r) { return (size_t)(cpart.hi[(size_t)r] - cpart.lo[(size_t)r]) * M * p->elem; };  // bytes
     if (!p->real) {
         for (int src = 0; src < R; ++src)
             for (int dst = 0; dst < R; ++dst)
                 if (src != dst)
-                    (void)hipMemcpyAsync(coarse.loc[(size_t)dst].F + off(src), coarse.loc[(size_t)src].F + off(src),
-                                         cnt(src) * sizeof(double), hipMemcpyDeviceToDevice, c.stream);
+                    (void)hipMemcpyAsync((char *)coarse.loc[(size_t)dst].F + off(src), (char *)coarse.loc[(size_t)src].F + off(src),
+                                         cnt(src), hipMemcpyDeviceToDevice, c.stream);
         return;
     }
     const int me = p->local[0];
-    double *F = coarse.loc[0].F;
+    char *F = (char *)coarse.loc[0].F;
     comm_group_begin();
     for (int r = 0; r < R; ++r) {
         if (r == me) continue;
@@ -293,9 +301,14 @@ void run(mg_slab_plan *p)
 
             if (cur.collapsed) {
                 const int rec = add_record(p, -1, cur.N, step, 1);
-                for (size_t i = 0; i < p->local.size(); ++i)
-                    mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), M,
-                                       nxt.loc[i].F);
+                for (size_t i = 0; i < p->local.size(); ++i) {
+                    if (p->mixed)
+                        mg_smooth_restrict_f32(cur.N, p->L, nullptr, (float *)cur.loc[i].U, (float *)cur.loc[i].F, step,
+                                               raw_slot(p, (size_t)rec, i), M, (float *)nxt.loc[i].F);
+                    else
+                        mg_smooth_restrict(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), M,
+                                           nxt.loc[i].F);
+                }
                 // levels N <= 64: the rest of this descent and its way back up in one launch
                 // (every rank walks the same slice, so tokens and records stay in step)
                 k::TailArgs ta;
@@ -311,14 +324,24 @@ void run(mg_slab_plan *p)
                         k::TailArgs mine = ta;
                         for (int i = 0; i < mine.n_nodes; ++i)  // error slots index raw_dev directly
                             if (mine.nodes[i].type != 0) mine.nodes[i].err_slot = (int)((size_t)rec_of[i] * p->local.size() + li);
-                        mine.F_top = nxt.loc[li].F;
-                        mine.U_top = nxt.loc[li].U;
                         mine.err_dev = p->raw_dev;
                         mine.gs_state = c.gs_state;
                         ProfScope ps("coarse_tail", M, 0.0);
-                        k::tail_launch(c.stream, mine);
+                        if (p->mixed) {
+                            k::TailArgsF f = tail_args_f32(mine);
+                            f.F_top = (const float *)nxt.loc[li].F;
+                            f.U_top = (float *)nxt.loc[li].U;
+                            k::tail_launch_f32(c.stream, f);
+                        } else {
+                            mine.F_top = nxt.loc[li].F;
+                            mine.U_top = nxt.loc[li].U;
+                            k::tail_launch(c.stream, mine);
+                        }
                     }
                     tok = tk;
+                } else if (p->mixed && M <= k::TAIL_MAX_N) {
+                    p->status = 15;  // mixed precision needs the coarse part of the file inside the tail kernel
+                    break;
                 }
             } else {
                 const int rec = add_record(p, -1, cur.N, step, 0);
@@ -333,7 +356,11 @@ void run(mg_slab_plan *p)
                     sf.fc_w = nxt.collapsed ? RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]} : window_of(nxt.part, r);
                     // U starts from zero on every descent (:252-257; a restart inside one file is
                     // not supported in slab mode), so no U ghost exchange is needed before the launch
-                    slab_smooth(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
+                    if (p->mixed)
+                        slab_smooth_f32(cur.N, p->L, nullptr, (float *)cur.loc[i].U, (const float *)cur.loc[i].F, step,
+                                        raw_slot(p, (size_t)rec, i), sf);
+                    else
+                        slab_smooth(cur.N, p->L, nullptr, cur.loc[i].U, cur.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
                 }
                 p->levels.push_back(nxt);
                 Level &fine_lv = p->levels[p->levels.size() - 2], &next_lv = p->levels.back();
@@ -353,6 +380,7 @@ void run(mg_slab_plan *p)
             Level &cur = p->levels.back();
             if (!cur.collapsed) { p->status = 12; break; }  // the exact solver runs on collapsed levels only
             if ((int)opt != 1) { p->status = 5; break; }
+            if (p->mixed) { p->status = 15; break; }  // an exact solve outside the tail kernel: fp64 mode only
             add_record(p, 0, cur.N, 0, 1);
             for (size_t i = 0; i < p->local.size(); ++i) mg_doExactSolver(cur.N, p->L, cur.loc[i].U, cur.loc[i].F, tol, 1);
         } else if (node == 1) {  // prolong + add + smooth, :329-424
@@ -365,8 +393,12 @@ void run(mg_slab_plan *p)
             if (fine.collapsed) {
                 const int rec = add_record(p, 1, fine.N, step, 1);
                 for (size_t i = 0; i < p->local.size(); ++i) {
-                    mg_prolong_smooth(coarse.N, coarse.loc[i].U, fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F,
-                                      step, raw_slot(p, (size_t)rec, i));
+                    if (p->mixed)
+                        mg_prolong_smooth_f32(coarse.N, (const float *)coarse.loc[i].U, fine.N, p->L, (const float *)fine.loc[i].U,
+                                              (float *)fine.loc[i].D, (float *)fine.loc[i].F, step, raw_slot(p, (size_t)rec, i));
+                    else
+                        mg_prolong_smooth(coarse.N, coarse.loc[i].U, fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F,
+                                          step, raw_slot(p, (size_t)rec, i));
                     std::swap(fine.loc[i].U, fine.loc[i].D);
                 }
             } else {
@@ -381,7 +413,11 @@ void run(mg_slab_plan *p)
                     sf.Nc = coarse.N;
                     sf.coarse = coarse.loc[i].U;
                     sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse.part, r);
-                    slab_smooth(fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
+                    if (p->mixed)
+                        slab_smooth_f32(fine.N, p->L, (const float *)fine.loc[i].U, (float *)fine.loc[i].D, (const float *)fine.loc[i].F,
+                                        step, raw_slot(p, (size_t)rec, i), sf);
+                    else
+                        slab_smooth(fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
                     std::swap(fine.loc[i].U, fine.loc[i].D);
                 }
             }
@@ -433,6 +469,13 @@ int mg_slab_ghost_rows(void) { return GHOST; }
 // nranks > 1).  rank == -1: all nranks slabs live in this process (virtual ranks).
 mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N)
 {
+    return mg_slab_load_flags(path, nranks, rank, collapse_N, 0);
+}
+
+// flags: MG_CYCLE_MIXED = fp32 fields for the whole cycle (source rounded once per slab, exact solver
+// in fp64 inside the tail kernel, result widened); everything else as mg_slab_load
+mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int collapse_N, int flags)
+{
     if (!require_ready("mg_slab_load")) return nullptr;
     std::ifstream f(path);
     if (!f.is_open()) {
@@ -441,6 +484,8 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
     }
     mg_slab_plan *p = new mg_slab_plan;
     p->path = path;
+    p->mixed = (flags & MG_CYCLE_MIXED) != 0;
+    p->elem = p->mixed ? sizeof(float) : sizeof(double);
     if (!(f >> p->L >> p->min_x >> p->min_y >> p->con_step >> p->con_N >> p->N_max >> p->N_min)) {
         fail(MG_ERR_CYCLE_FILE, "%s: malformed cycle structure header", path);
         delete p;
@@ -505,7 +550,17 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
     for (size_t i = 0; i < p->local.size(); ++i) {
         const RowWindow w = window_of(top.part, p->local[i]);
         const int lo = std::max(0, w.base), hi = std::min(top.N, w.base + w.rows);
-        fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(top.loc[i].F, w, top.N, lo));
+        if (!p->mixed) {
+            fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(top.loc[i].F, w, top.N, lo));
+            continue;
+        }
+        // mixed: the fp64 source rows go through the widened-result buffer and are rounded once
+        double *tmp = (double *)p->pool.get((size_t)w.rows * top.N * sizeof(double));
+        if (!tmp) { mg_slab_destroy(p); return nullptr; }
+        p->U64.push_back(tmp);
+        const size_t n = (size_t)(hi - lo) * top.N;
+        fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, tmp);
+        k::convert_to_f32(ctx().stream, (float *)row_at(p, top.loc[i].F, w, top.N, lo), tmp, n);
     }
     p->levels.push_back(top);
     (void)hipEventCreate(&p->ev0);
@@ -562,9 +617,15 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
     // over the slabs in rank order
     Level &top = p->levels[0];
     const size_t nloc = p->local.size(), nrec = p->records.size();
-    for (size_t i = 0; i < nloc && p->want_error; ++i)
-        k::analytic_error_rows(c.stream, top.N, p->L, top.loc[i].U, window_of(top.part, p->local[i]), p->min_x, p->min_y,
-                               raw_slot(p, p->max_rec, i));
+    for (size_t i = 0; i < nloc && p->want_error; ++i) {
+        const RowWindow w = window_of(top.part, p->local[i]);
+        const double *U = top.loc[i].U;
+        if (p->mixed) {  // widen the whole window (exact); the kernel reads the owned rows
+            k::convert_to_f64(c.stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
+            U = p->U64[i];
+        }
+        k::analytic_error_rows(c.stream, top.N, p->L, U, w, p->min_x, p->min_y, raw_slot(p, p->max_rec, i));
+    }
     std::vector<double> raw((p->max_rec + 1) * (size_t)p->nranks, 0.0);  // [slot][global rank]
     if (p->real) {
         comm_allgather(p->raw_dev, p->all_dev, p->max_rec + 1);  // nloc == 1: [slot] per rank
@@ -610,8 +671,12 @@ int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
     Level &top = p->levels[0];
     for (size_t i = 0; i < p->local.size(); ++i) {
         const RowWindow w = window_of(top.part, p->local[i]);
-        mg_download(host_full + (size_t)w.own_lo * top.N, row_ptr(top.loc[i].U, w, top.N, w.own_lo),
-                    (size_t)(w.own_hi - w.own_lo) * top.N);
+        double *U = top.loc[i].U;
+        if (p->mixed) {
+            k::convert_to_f64(ctx().stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
+            U = p->U64[i];
+        }
+        mg_download(host_full + (size_t)w.own_lo * top.N, row_ptr(U, w, top.N, w.own_lo), (size_t)(w.own_hi - w.own_lo) * top.N);
     }
     return 0;
 }
@@ -629,6 +694,7 @@ void mg_slab_destroy(mg_slab_plan *p)
     p->levels.clear();
     if (p->raw_dev) p->pool.put(p->raw_dev);
     if (p->all_dev) p->pool.put(p->all_dev);
+    for (double *b : p->U64) p->pool.put(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     p->pool.trim();

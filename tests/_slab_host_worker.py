@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     cycle_path, want_path, collapse = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import multigrid_poisson_solver_amd as mg
@@ -35,7 +36,7 @@ def main():
     mg.comm_init_host(rank, world, exchange, allgather)
     want = np.load(want_path)
     N = int(want["N"])
-    plan = mg.SlabPlan(cycle_path, world, rank, collapse)
+    plan = mg.SlabPlan(cycle_path, world, rank, collapse, mixed=mixed)
     for run in range(2):  # the second window re-runs on the state the first one left behind
         res = plan.execute()
         assert res["status"] == 0, res

@@ -133,3 +133,29 @@ def test_command_line_program_mixed(mg, cycle_dir, tmp_path):
     assert runs["mixed"].shape == runs["f64"].shape
     assert 0 < np.abs(runs["mixed"] - runs["f64"]).max() <= 2e-5 * scale
     assert np.abs(runs["refine"] - runs["f64"]).max() <= 0.5 * scale   # another iterate, same problem
+
+
+@pytest.mark.parametrize("R,collapse", [(2, 64), (3, 256), (8, 128)])
+def test_mixed_slabs_virtual_ranks_vs_numpy(mg, oracle, tmp_path, R, collapse):
+    """fp32 row slabs (virtual ranks on one GPU): the result and the errors are those of the
+    single-GPU fp32 cycle, i.e. of the numpy restatement, bit for bit."""
+    N = 1024
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    toks = open(path).read().split()
+    sizes, n = [], N
+    while n >= 8:
+        sizes.append(n)
+        n //= 2
+    U32, recs = o32.run_cycle_tokens(mg, oracle, oracle.getSource(N), 1.0, 3, sizes, toks[7:])
+    plan = mg.SlabPlan(path, R, -1, collapse, mixed=True)
+    for _ in range(2):
+        got = plan.execute()
+        assert got["status"] == 0
+        assert np.array_equal(plan.gather_U(N), U32.astype(np.float64))
+        assert [(g[0], g[1]) for g in got["records"]] == [(w[0], w[1]) for w in recs]
+        for g, w in zip(got["records"], recs):
+            assert g[3] == pytest.approx(w[2], rel=1e-10, abs=1e-300)
+    single = mg.CyclePlan(path, fused=True, mixed=True).execute()
+    assert got["mg_error"] == pytest.approx(single["mg_error"], rel=1e-10)
+    plan.close()
