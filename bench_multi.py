@@ -22,9 +22,12 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0
 
 
-def grid_for(world, base=8192):
+def grid_for(world, base=8192, mixed=False):
     n = base * math.sqrt(world)
-    return int(round(n / 64.0)) * 64
+    # the fp32 kernels exist in the fused form only, which needs an even size on every level above the
+    # coarse tail (N > 64): multiples of 2048 (12288, 16384, 22528 for 2, 4, 8 GPUs)
+    q = 2048.0 if mixed else 64.0
+    return int(round(n / q)) * int(q)
 
 
 def host_transport(mg, rank, world):
@@ -65,7 +68,7 @@ def run(args, rank, world, local_rank):
         dist.broadcast_object_list(uid, src=0)
         mg.comm_init(rank, world, uid[0])
 
-    N = grid_for(world, args.n) if args.n == 8192 else args.n
+    N = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n
     nu = args.nu
     sizes = level_sizes(N, args.n_min)
     tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
