@@ -199,7 +199,7 @@ def main():
 
     out = {
         "metric": "vcycle_mlups", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
         "config": {"workload": f"{args.cycle}({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'}, {len(sizes)} levels to N={sizes[-1]}, "
                                f"red-black GS(1e-7) coarse solve, cycle-file driver ({args.mode}, {args.smoother} smoother)",

@@ -245,7 +245,8 @@ int  mg_comm_size(void);
 
 /* host-only: row ranges per level and rank of the hierarchy N_max, N_max/2, ... >= N_min.
  * out[(level*nranks + rank)*2 + {0,1}] = [lo, hi); collapsed_out[level] = 1 where the level
- * lives on rank 0 only.  Returns the number of levels. */
+ * is collapsed (replicated whole on every rank; reported as [0, N) for rank 0 and [0, 0) for the
+ * others).  Returns the number of levels. */
 int  mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out);
 int  mg_slab_ghost_rows(void);
 
@@ -253,7 +254,7 @@ typedef struct mg_slab_plan mg_slab_plan;
 /* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:
  * all nranks slabs live in this process and exchange by device copies ("virtual ranks":
  * how the decomposition is verified bit for bit on one GPU).  Levels with N <= collapse_N
- * run on rank 0 only.  Supported grammar: con_N = 1, fixed con_step in 1..4, option 1. */
+ * are replicated: every rank runs them on the whole grid.  Supported grammar: con_N = 1, fixed con_step in 1..4, option 1. */
 mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_N);
 /* the same with flags: MG_CYCLE_MIXED = the whole cycle on fp32 slabs (half the HBM and xGMI bytes;
  * source rounded once, exact solver in fp64, mg_slab_gather_U widens), BASELINE.json configs[4] */

@@ -436,7 +436,7 @@ extern "C" {
 int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 
 // host-only: the row ranges each rank owns on every level of the hierarchy a cycle file
-// generates (N_max, halving down to N_min), and which levels are collapsed onto rank 0.
+// generates (N_max, halving down to N_min), and which levels are collapsed (replicated on every rank).
 // out[(level*nranks + rank)*2 + {0,1}] = {lo, hi}; collapsed levels report {0, N} for rank 0
 // and {0, 0} for the others.  Returns the number of levels.
 int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out)
