@@ -181,11 +181,16 @@ struct GhostItem {
     Level *lv;
     Which which;
 };
-void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items)
+void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group);
+
+// `share`/`share_part`: the collapse all-gather of the next level's F rides in the same group
+void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level *share = nullptr,
+                     const Partition *share_part = nullptr)
 {
     Context &c = ctx();
     const int R = p->nranks;
-    if (items.empty() || R == 1) return;
+    if (R == 1) return;
+    if (items.empty() && !share) return;
     if (p->real) comm_group_begin();
     for (const GhostItem &it : items) {
         Level &lv = *it.lv;
@@ -216,13 +221,14 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items)
             comm_recv(row_at(p, A, w, N, w.own_lo - GHOST), cnt, r - 1);
         }
     }
+    if (share) share_rows(p, *share, *share_part, true);
     if (p->real) comm_group_end();
 }
 
 // collapse boundary: every rank wrote its rows [cpart.lo, cpart.hi) of the coarse F into its own
 // full M x M array; afterwards every rank holds all rows (an all-gather with per-rank row
 // counts, issued as one group of point-to-point transfers)
-void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart)
+void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group)
 {
     Context &c = ctx();
     const int M = coarse.N, R = p->nranks;
@@ -239,13 +245,13 @@ void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart)
     }
     const int me = p->local[0];
     char *F = (char *)coarse.loc[0].F;
-    comm_group_begin();
+    if (!in_open_group) comm_group_begin();
     for (int r = 0; r < R; ++r) {
         if (r == me) continue;
         comm_send(F + off(me), cnt(me), r);
         comm_recv(F + off(r), cnt(r), r);
     }
-    comm_group_end();
+    if (!in_open_group) comm_group_end();
 }
 
 double *raw_slot(mg_slab_plan *p, size_t rec, size_t local_i) { return p->raw_dev + rec * p->local.size() + local_i; }
@@ -369,8 +375,8 @@ void run(mg_slab_plan *p)
                 std::vector<GhostItem> items;
                 items.push_back(GhostItem{&fine_lv, ARR_U});
                 if (!next_lv.collapsed) items.push_back(GhostItem{&next_lv, ARR_F});
-                exchange_ghosts(p, items);
-                if (next_lv.collapsed) share_rows(p, next_lv, cpart);
+                // ... and, at the collapse boundary, the all-gather of the next level's F rows
+                exchange_ghosts(p, items, next_lv.collapsed ? &next_lv : nullptr, &cpart);
                 continue;
             }
             p->levels.push_back(nxt);
