@@ -58,6 +58,9 @@ struct ProlongTable {
 // owns [own_lo, own_hi).  1-D row-slab decomposition, BASELINE.json north_star.
 struct RowWindow {
     int base = 0, rows = 0, own_lo = 0, own_hi = 0;
+    // rows that count towards the error norm; -1: the rows [own_lo, own_hi).  A slab launch may
+    // update more rows than its rank owns (redundant halo rows instead of a ghost exchange).
+    int norm_lo = -1, norm_hi = -1;
 };
 
 // ---------------------------------------------------------------------------

@@ -5,8 +5,13 @@
 // contiguous block of the row-major array and a ghost row is one contiguous message.  Each
 // slab carries GHOST rows of halo on either side.  Because the smoother is temporally
 // blocked, ONE exchange of ghost rows feeds a whole fused node (S sweeps + residual +
-// restriction, or prolongation + S sweeps): per level and V-cycle there is one exchange of
-// the next level's F on the way down and one of (coarse U, fine U) on the way up.
+// restriction, or prolongation + S sweeps): per level and V-cycle there is ONE exchange, on the
+// way down (the next level's F halo together with this level's U halo), and none on the way up:
+// a `1` node also updates the few halo rows of its level that the next finer level's
+// prolongation will read (at most 7 rows per side, the fixed point of e -> (e + S + 2)/2 + 1),
+// from inputs that are already there -- U and F halos from the descent, the coarse U rows it
+// computed redundantly itself one node earlier.  Redundant rows are bit-identical to the
+// neighbour's owned rows (same inputs, same arithmetic).
 // Levels at or below collapse_N are collapsed: after the last
 // distributed restriction every rank hands its rows of that level's F to the others, and
 // EVERY rank -- rank 0 included -- runs that part of the cycle file on the whole coarse grid
@@ -21,6 +26,7 @@
 // The coarse partition is induced by the fine one: a rank owns the coarse rows whose
 // lower-left restriction sample (doRestriction's iy_f, src/MG_solver_CPU.cpp:662) lies in
 // its fine rows, so the fused restriction never writes a remote row.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -33,7 +39,9 @@
 namespace mg {
 namespace {
 
-constexpr int GHOST = 6;  // >= S+2 for S <= 4 sweeps per launch (mg_stream.hip Halo<>)
+// Halo rows per side.  S+2 would do for one fused node (mg_stream_impl.h Halo<>); 12 also covers the
+// rows a rank computes REDUNDANTLY on the way up (see ext below), so that the ascent needs no exchange.
+constexpr int GHOST = 12;
 
 struct Partition {
     std::vector<int> lo, hi;  // rows [lo[r], hi[r]) owned by global rank r
@@ -121,6 +129,10 @@ struct mg_slab_plan {
     bool mixed = false;   // MG_CYCLE_MIXED: fp32 fields (the double* members then only carry addresses)
     size_t elem = sizeof(double);
     std::vector<double *> U64;   // mixed: per local rank, the finest window widened to fp64 (result / error)
+    // per hierarchy index and GLOBAL rank: the rows a `1` node updates = owned rows + the halo rows the
+    // next finer level's `1` node reads through the prolongation (distributed levels only)
+    std::vector<std::vector<std::pair<int, int>>> ext;
+    bool poison = false;         // MG_SLAB_POISON: fresh level arrays are filled with NaN (tests)
 };
 
 namespace {
@@ -160,6 +172,10 @@ void alloc_level(mg_slab_plan *p, Level &lv)
         lv.loc[i].U = (double *)p->pool.get(bytes);
         lv.loc[i].F = (double *)p->pool.get(bytes);
         lv.loc[i].D = (double *)p->pool.get(bytes);
+        if (p->poison) {  // all-ones bytes are a NaN in fp64 and in fp32: a row nobody wrote shows up in the result
+            for (double *a : {lv.loc[i].U, lv.loc[i].F, lv.loc[i].D})
+                if (a) (void)hipMemsetAsync(a, 0xFF, bytes, ctx().stream);
+        }
     }
 }
 
@@ -409,13 +425,17 @@ void run(mg_slab_plan *p)
                 }
             } else {
                 const int rec = add_record(p, 1, fine.N, step, 0);
-                // the fine level's U halo was exchanged right after its descent; a distributed coarse
-                // level's U was just produced and needs its halo now, a collapsed one is whole
-                if (!coarse.collapsed) exchange_ghosts(p, {GhostItem{&coarse, ARR_U}});
+                // no exchange: the fine level's U and F halos came with its descent, and the halo rows of the
+                // coarse U that this launch reads were computed by this rank itself (ext, see mg_slab_load)
+                const size_t hier = (size_t)at;  // hierarchy index of the fine level
                 for (size_t i = 0; i < p->local.size(); ++i) {
                     const int r = p->local[i];
                     SlabFusion sf;
                     sf.fine_w = window_of(fine.part, r);
+                    sf.fine_w.norm_lo = sf.fine_w.own_lo;  // the error counts owned rows only
+                    sf.fine_w.norm_hi = sf.fine_w.own_hi;
+                    sf.fine_w.own_lo = p->ext[hier][(size_t)r].first;
+                    sf.fine_w.own_hi = p->ext[hier][(size_t)r].second;
                     sf.Nc = coarse.N;
                     sf.coarse = coarse.loc[i].U;
                     sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse.part, r);
@@ -541,6 +561,42 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
         delete p;
         return nullptr;
     }
+    // rows each `1` node updates: owned rows plus what the next finer level's `1` node will read of this
+    // level through the prolongation (rows orow[y], orow[y]+1 for every fine row y the launch loads)
+    {
+        const int H = p->con_step + 2;  // input rows a launch loads beyond the rows it updates (Halo<S> + 1 spare)
+        p->ext.resize(nl);
+        for (size_t l = 0; l < nl && !p->level_collapsed[l]; ++l) {
+            p->ext[l].resize((size_t)nranks);
+            std::vector<int> owner;
+            std::vector<double> wh, wl;
+            if (l > 0) {
+                owner.resize((size_t)p->sizes[l - 1]);
+                wh.resize(owner.size());
+                wl.resize(owner.size());
+                build_prolongation_table(p->sizes[l], p->sizes[l - 1], 0, owner.data(), wh.data(), wl.data());
+            }
+            for (int r = 0; r < nranks; ++r) {
+                int lo = p->parts[l].lo[(size_t)r], hi = p->parts[l].hi[(size_t)r];
+                if (l > 0) {
+                    const int Nf = p->sizes[l - 1], Nc = p->sizes[l];
+                    const int first = std::max(0, p->ext[l - 1][(size_t)r].first - H);
+                    const int last = std::min(Nf, p->ext[l - 1][(size_t)r].second + H) - 1;
+                    lo = std::min(lo, std::max(0, owner[(size_t)first]));
+                    hi = std::max(hi, std::min(Nc, owner[(size_t)last] + 2));
+                }
+                const int own_lo = p->parts[l].lo[(size_t)r], own_hi = p->parts[l].hi[(size_t)r];
+                if (own_lo - lo + H > GHOST || hi - own_hi + H > GHOST) {
+                    fail(MG_ERR_UNSUPPORTED, "row-slab mode: level %d needs %d redundant rows, more than the halo holds", p->sizes[l],
+                         std::max(own_lo - lo, hi - own_hi));
+                    delete p;
+                    return nullptr;
+                }
+                p->ext[l][(size_t)r] = std::make_pair(lo, hi);
+            }
+        }
+    }
+    p->poison = getenv("MG_SLAB_POISON") != nullptr;
     size_t smoothing_nodes = 0;
     for (double t : p->tokens)
         if (t == -1.0 || t == 1.0 || t == 0.0) ++smoothing_nodes;

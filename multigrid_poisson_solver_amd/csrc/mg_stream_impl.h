@@ -93,6 +93,7 @@ struct StreamParams {
     // row row_base and hold rows_local rows; this launch updates rows [own_y0, own_y1).
     // Single GPU: row_base = 0, rows_local = N, own = [0, N).
     int row_base, rows_local, own_y0, own_y1;
+    int norm_y0, norm_y1;           // rows counted in the error norm (a subset of the updated rows)
     int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
     int raw_norm;                   // error output is the raw sum over the owned rows
     int nt_min_n;                   // grids at least this large store U/D non-temporally
@@ -508,6 +509,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             if (want_res) {
                 const int y = yin - S - 1;
                 const bool mine = y >= y0 && y < y1 && lane_owns;  // each point counted once
+                const bool counted = mine && y >= p.norm_y0 && y < p.norm_y1;
                 const bool row_edge = y <= 0 || y >= N - 1;
                 const Row<COLS> c = newer[S], so = older[S];
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const real_t dv = interior ? r : real_t(0.0);
                     d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
                     // (row+col) even interior points only, :610/:617
-                    if (mine && interior && (((y & 1) == 0) == col_even[j])) acc += fabs((double)r);  // norms are accumulated in fp64 whatever the field type
+                    if (counted && interior && (((y & 1) == 0) == col_even[j])) acc += fabs((double)r);  // norms are accumulated in fp64 whatever the field type
                 }
                 if (mine && p.D) store_row<COLS>(p.D + (size_t)(y - p.row_base) * N + xl, d, nt_stores);
 
@@ -666,6 +668,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.rows_local = fine_w ? fine_w->rows : N;
     p.own_y0 = fine_w ? fine_w->own_lo : 0;
     p.own_y1 = fine_w ? fine_w->own_hi : N;
+    p.norm_y0 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_lo : p.own_y0;
+    p.norm_y1 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_hi : p.own_y1;
     p.raw_norm = fine_w ? 1 : 0;
     static const int nt_min = [] { const char *e = getenv("MG_NT_MIN_N"); return e ? atoi(e) : 2048; }();
     p.nt_min_n = nt_min;

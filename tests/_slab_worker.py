@@ -1,7 +1,7 @@
 """World-size-N gloo worker (CPU): emulates the row-slab V-cycle of mg_slab.cpp with the CPU
 oracle as the local operator.  Every rank holds full-size arrays that are NaN outside its
 window (owned rows + GHOST halo rows), applies the oracle's whole-grid operators, exchanges
-exactly the ghost rows the engine exchanges (over torch.distributed/gloo) and finally the
+exactly the ghost rows the engine exchanges (on the way down only; nothing on the way up) (over torch.distributed/gloo) and finally the
 assembled finest U must equal the oracle's single-domain result bit for bit with no NaN in
 any owned row -- which proves the partition (mg_slab_partition, the product's host code), the
 halo depth and the exchange schedule.  TEST INFRASTRUCTURE (uses oracle/).
@@ -128,13 +128,10 @@ def main():
     for l in range(first_collapsed - 1, -1, -1):
         n, M = sizes[l], sizes[l + 1]
         lo, hi = own[l]
-        if l + 1 < first_collapsed:  # distributed coarse level: its ghost rows come from the neighbours
-            clo, chi = own[l + 1]
-            Uc = np.full((M, M), np.nan)
-            Uc[clo:chi] = U[l + 1][clo:chi]
-            exchange(Uc, clo, chi, G, rank, world)
-        else:
-            Uc = U[l + 1]
+        # NO exchange on the way up: the coarse halo rows this level reads through the prolongation are
+        # the ones this rank computed redundantly itself (whole-grid operators on NaN-poisoned windows
+        # compute every row whose inputs are there); GHOST is sized so that this reaches far enough
+        Uc = U[l + 1]
         Uf = U[l]  # owned rows + the halo exchanged right after this level's descent
         Uf = orc.doGridAddition(n, Uf, orc.doProlongation(M, Uc, n, fill=np.nan))
         U[l], _ = orc.doSmoothing(n, L, Uf, F[l], step)

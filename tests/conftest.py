@@ -17,6 +17,9 @@ GOLDEN = os.path.join(HERE, "golden")
 # coarse-grid loops and a 100 ms solve takes minutes.  Bound the team before libgomp loads.
 os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# slab plans fill freshly allocated level arrays with NaN: a halo row that nobody wrote (no exchange, no
+# redundant computation) then shows up in the compared result instead of passing on stale data
+os.environ.setdefault("MG_SLAB_POISON", "1")
 
 
 def pytest_configure(config):

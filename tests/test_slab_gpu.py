@@ -145,3 +145,15 @@ def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse,
     out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"SLAB_HOST_TRANSPORT OK {world} {N} {collapse}" in out.stdout
+
+
+def test_fresh_slab_arrays_are_poisoned(mg, tmp_path):
+    """conftest sets MG_SLAB_POISON: the rows of a slab array that nobody has written are NaN, so a
+    missing halo row cannot hide behind stale data in the parity tests above."""
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, 512, 8, 3, 1e-7)
+    plan = mg.SlabPlan(path, 2, -1, 64)
+    assert np.isnan(plan.gather_U(512)).all()
+    assert plan.execute()["status"] == 0
+    assert not np.isnan(plan.gather_U(512)).any()
+    plan.close()
