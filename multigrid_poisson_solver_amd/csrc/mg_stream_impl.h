@@ -634,7 +634,7 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
 template <int S>
 void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
-    // rows in flight per lane: PF = 2 (a FIFO of 4 slots).  A deeper FIFO (PF = 4, 8) costs registers
+    // rows in flight per lane: PF = 2 (a FIFO of 4 slots).  A deeper FIFO (PF = 3 at the same occupancy, PF = 4, 8) costs registers
     // and a longer prologue and measured slower at every size from 128 to 8192 once all loads were
     // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).
     launch_variant<S, 2>(s, p, err_out);
