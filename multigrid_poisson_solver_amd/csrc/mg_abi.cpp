@@ -769,8 +769,12 @@ void mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, fl
                          M, &rt);
 }
 
-void mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out, float *F, int step,
-                           double *error_dev)
+}  // extern "C"
+
+namespace mg {
+namespace {
+void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out, double *U_out_wide,
+                             const float *F, int step, double *error_dev)
 {
     if (!require_ready("mg_prolong_smooth_f32") || !grid_args_ok("mg_prolong_smooth_f32", N) ||
         !grid_args_ok("mg_prolong_smooth_f32", Nc))
@@ -778,16 +782,33 @@ void mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const floa
     Context &c = ctx();
     const ProlongTable &pt = prolong_table(Nc, N);
     if (!pt.owner_row) return;
-    if (U_in == U_out || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !pt.fusable) {
+    if ((!U_out_wide && U_in == U_out) || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !pt.fusable) {
         fail(MG_ERR_UNSUPPORTED, "mg_prolong_smooth_f32: needs 1..%d steps, even N and a nested coarse size (Nc=%d N=%d step=%d)",
              k::stream_max_steps(), Nc, N, step);
         return;
     }
     const double dx2 = spacing_sq(N, L);
     const size_t n = (size_t)N * N;
-    ProfScope ps("jacobi_stream_f32<prolong>", N, (double)n * (12.0 * step + 8.0) + 4.0 * Nc * Nc);
+    ProfScope ps(U_out_wide ? "jacobi_stream_f32<prolong,widen>" : "jacobi_stream_f32<prolong>", N,
+                 (double)n * (12.0 * step + 8.0 + (U_out_wide ? 12.0 : 0.0)) + 4.0 * Nc * Nc);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,
-                         nullptr);
+                         nullptr, nullptr, nullptr, nullptr, U_out_wide);
+}
+}  // namespace
+
+void prolong_smooth_f32_wide(int Nc, const float *U_c, int N, double L, const float *U_in, double *U_out_wide, const float *F,
+                             int step, double *error_dev)
+{
+    prolong_smooth_f32_impl(Nc, U_c, N, L, U_in, nullptr, U_out_wide, F, step, error_dev);
+}
+}  // namespace mg
+
+extern "C" {
+
+void mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out, float *F, int step,
+                           double *error_dev)
+{
+    prolong_smooth_f32_impl(Nc, U_c, N, L, U_in, U_out, nullptr, F, step, error_dev);
 }
 
 float *mg_alloc_f32(size_t n)

@@ -281,6 +281,7 @@ struct Exec {
     int at = 0;  // len_flag
     int status = 0;
     bool capturing = false;
+    bool widened = false;  // mixed mode: the last node stored its result in fp64 (plan->U64) itself
 
     bool next(double *v)
     {
@@ -579,10 +580,20 @@ void run_nodes(Exec &x)
             if (mixed) {
                 if (step <= 0) { x.status = 15; break; }
                 const int rec = add_record(p, 1, fine->N, step);
-                mg_prolong_smooth_f32(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, (float *)fine->D,
-                                      (float *)fine->F, step, error_slot(p, rec));
+                // the node that ends the file on the finest level stores its result in fp64 straight away
+                // (single-cycle windows; a refinement adds the correction in a pass of its own)
+                const bool last_node = fine->N == p->N_max && p->refinements == 1 &&
+                                       (x.tok >= p->tokens.size() || (int)p->tokens[x.tok] == 2);
+                if (last_node) {
+                    prolong_smooth_f32_wide(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, p->U64,
+                                            (const float *)fine->F, step, error_slot(p, rec));
+                    x.widened = true;
+                } else {
+                    mg_prolong_smooth_f32(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, (float *)fine->D,
+                                          (float *)fine->F, step, error_slot(p, rec));
+                    std::swap(fine->U, fine->D);
+                }
                 if (x.c.last_error) { x.status = 15; break; }
-                std::swap(fine->U, fine->D);
                 cycle.Remove_back();  // :363
                 report_text(p, arrow);
                 report_smoothing(p, rec);
@@ -802,7 +813,8 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         p->final_N = last->N;
         if (mixed && status == 0 && last->N == p->N_max) {
             // fp64 correction: U64 = (double)e on the first cycle, U64 += (double)e afterwards
-            if (it == 0) k::convert_to_f64(s, p->U64, (const float *)last->U, n_top);
+            if (x.widened) { /* the last node stored fp64 already */ }
+            else if (it == 0) k::convert_to_f64(s, p->U64, (const float *)last->U, n_top);
             else k::add_widened(s, p->U64, (const float *)last->U, n_top);
             p->final_U = p->U64;
         } else if (mixed && status == 0) {

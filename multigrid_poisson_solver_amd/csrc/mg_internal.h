@@ -226,7 +226,7 @@ void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2
 void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                        double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
                        const RestrictTable *rt, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
-                       const RowWindow *fc_w = nullptr);
+                       const RowWindow *fc_w = nullptr, double *out_wide = nullptr);
 // coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
 constexpr int TAIL_MAX_LEVELS = 6;
 constexpr int TAIL_MAX_NODES = 48;
@@ -268,6 +268,9 @@ void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const 
 int  gs_single_workgroup_max_n();
 }  // namespace k
 
+// mg_prolong_smooth_f32 whose result goes to an fp64 array (exact widening in the store) instead of U_out
+void prolong_smooth_f32_wide(int Nc, const float *U_c, int N, double L, const float *U_in, double *U_out_wide, const float *F,
+                             int step, double *error_dev);
 // fp32 view of a coarse-tail slice: spacings and transfer weights rounded once (mg_cycle.cpp)
 k::TailArgsF tail_args_f32(const k::TailArgs &a);
 // collect the coarse-tail slice of a cycle file's node stream (mg_cycle.cpp)

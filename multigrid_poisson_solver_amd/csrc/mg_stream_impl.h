@@ -94,6 +94,7 @@ struct StreamParams {
     // Single GPU: row_base = 0, rows_local = N, own = [0, N).
     int row_base, rows_local, own_y0, own_y1;
     int norm_y0, norm_y1;           // rows counted in the error norm (a subset of the updated rows)
+    double *out_wide;               // fp32 fields only: store the result as fp64 here instead of `out`
     int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
     int raw_norm;                   // error output is the raw sum over the owned rows
     int nt_min_n;                   // grids at least this large store U/D non-temporally
@@ -502,7 +503,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // nw is level S of row yin-S: the smoothed U
             {
                 const int y = yin - S;
-                if (y >= y0 && y < y1 && lane_owns) store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw, nt_stores);
+                if (y >= y0 && y < y1 && lane_owns) {
+                    if (sizeof(real_t) != sizeof(double) && p.out_wide) {
+                        // mixed precision: the last node of a cycle hands its result over in fp64 (exact
+                        // widening) instead of leaving it to a separate conversion pass
+                        double *w = p.out_wide + (size_t)(y - p.row_base) * N + xl;
+#pragma unroll
+                        for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
+                    } else {
+                        store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw, nt_stores);
+                    }
+                }
             }
 
             // residual stage, row yin-S-1 (src/MG_solver_CPU.cpp:560 and the error sums :611)
@@ -645,7 +656,8 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 // field type real_t; tb carries the tables the fused stages need
 inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps,
                 double *err_out, real_t *D_out, int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M,
-                const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w)
+                const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
+                double *out_wide = nullptr)
 {
     if (steps < 1 || steps > MAX_S) {
         fail(MG_ERR_ARG, "jacobi_stream: %d sweeps per launch (1..%d)", steps, MAX_S);
@@ -662,6 +674,7 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.in = in;
     p.F = F;
     p.out = out;
+    p.out_wide = out_wide;
     p.D = D_out;
     p.d_sign = d_sign;
     p.row_base = fine_w ? fine_w->base : 0;
