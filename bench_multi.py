@@ -24,10 +24,7 @@ HBM_PEAK_GBS = 8000.0
 
 def grid_for(world, base=8192, mixed=False):
     n = base * math.sqrt(world)
-    # the fp32 kernels exist in the fused form only, which needs an even size on every level above the
-    # coarse tail (N > 64): multiples of 2048 (12288, 16384, 22528 for 2, 4, 8 GPUs)
-    q = 2048.0 if mixed else 64.0
-    return int(round(n / q)) * int(q)
+    return int(round(n / 64.0)) * 64
 
 
 def host_transport(mg, rank, world):

@@ -757,16 +757,32 @@ void mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, fl
     Context &c = ctx();
     const RestrictTable &rt = restrict_table(N, M);
     if (!rt.lo) return;
-    if (U_in != nullptr || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !rt.fusable) {
-        fail(MG_ERR_UNSUPPORTED, "mg_smooth_restrict_f32: needs a zero start, 1..%d steps, even N and a nested coarse size (N=%d M=%d step=%d)",
+    if (U_in != nullptr || step < 1 || step > k::stream_max_steps()) {
+        fail(MG_ERR_UNSUPPORTED, "mg_smooth_restrict_f32: needs a zero start and 1..%d steps (N=%d M=%d step=%d)",
              k::stream_max_steps(), N, M, step);
         return;
     }
     const double dx2 = spacing_sq(N, L);
     const size_t n = (size_t)N * N;
-    ProfScope ps("jacobi_stream_f32<zero,res,restrict>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
-    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, nullptr, 0, nullptr, F_c,
-                         M, &rt);
+    if (k::stream_fusable(N) && rt.fusable) {
+        ProfScope ps("jacobi_stream_f32<zero,res,restrict>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
+        k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, nullptr, 0, nullptr, F_c,
+                             M, &rt);
+        return;
+    }
+    // odd or non-nested sizes: operator by operator (sweeps + signed residual in one launch, then the gather)
+    float *D = (float *)scratch_pool().get(n * sizeof(float));
+    if (!D) return;
+    {
+        ProfScope ps("jacobi_stream_f32<zero,res>", N, (double)n * (12.0 * step + 4.0 + 12.0));
+        k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, nullptr, 0, nullptr,
+                             nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, D, -1);
+    }
+    {
+        ProfScope ps("restrict_f32", N, 4.0 * N * N + 4.0 * M * M);
+        k::restrict_gather_f32(c.stream, N, D, M, F_c, rt, +1);
+    }
+    scratch_pool().put(D);
 }
 
 }  // extern "C"
@@ -782,13 +798,33 @@ void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const fl
     Context &c = ctx();
     const ProlongTable &pt = prolong_table(Nc, N);
     if (!pt.owner_row) return;
-    if ((!U_out_wide && U_in == U_out) || step < 1 || step > k::stream_max_steps() || !k::stream_fusable(N) || !pt.fusable) {
-        fail(MG_ERR_UNSUPPORTED, "mg_prolong_smooth_f32: needs 1..%d steps, even N and a nested coarse size (Nc=%d N=%d step=%d)",
+    if ((!U_out_wide && U_in == U_out) || step < 1 || step > k::stream_max_steps()) {
+        fail(MG_ERR_UNSUPPORTED, "mg_prolong_smooth_f32: needs 1..%d steps and U_out != U_in (Nc=%d N=%d step=%d)",
              k::stream_max_steps(), Nc, N, step);
         return;
     }
     const double dx2 = spacing_sq(N, L);
     const size_t n = (size_t)N * N;
+    if (!k::stream_fusable(N) || !pt.fusable) {
+        // odd or non-nested sizes: prolongation + addition as a gather, then the sweeps
+        if (U_out_wide) {
+            fail(MG_ERR_UNSUPPORTED, "mg_prolong_smooth_f32: the widening store needs the fused form (Nc=%d N=%d)", Nc, N);
+            return;
+        }
+        float *tmp = (float *)scratch_pool().get(n * sizeof(float));
+        if (!tmp) return;
+        {
+            ProfScope ps("prolong_add_f32", N, 4.0 * Nc * Nc + 8.0 * N * N);
+            k::prolong_add_f32(c.stream, Nc, U_c, N, U_in, tmp, pt);
+        }
+        {
+            ProfScope ps("jacobi_stream_f32", N, (double)n * 12.0 * step);
+            k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), tmp, F, U_out, step, error_dev, nullptr, 0, nullptr, nullptr,
+                                 0, nullptr);
+        }
+        scratch_pool().put(tmp);
+        return;
+    }
     ProfScope ps(U_out_wide ? "jacobi_stream_f32<prolong,widen>" : "jacobi_stream_f32<prolong>", N,
                  (double)n * (12.0 * step + 8.0 + (U_out_wide ? 12.0 : 0.0)) + 4.0 * Nc * Nc);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,

@@ -582,7 +582,8 @@ void run_nodes(Exec &x)
                 const int rec = add_record(p, 1, fine->N, step);
                 // the node that ends the file on the finest level stores its result in fp64 straight away
                 // (single-cycle windows; a refinement adds the correction in a pass of its own)
-                const bool last_node = fine->N == p->N_max && p->refinements == 1 &&
+                const bool last_node = fine->N == p->N_max && p->refinements == 1 && k::stream_fusable(fine->N) &&
+                                       prolong_table(coarse->N, fine->N).fusable &&
                                        (x.tok >= p->tokens.size() || (int)p->tokens[x.tok] == 2);
                 if (last_node) {
                     prolong_smooth_f32_wide(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, p->U64,

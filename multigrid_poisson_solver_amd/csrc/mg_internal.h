@@ -207,6 +207,8 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);
+void restrict_gather_f32(hipStream_t s, int N, const float *Uf, int M, float *Uc, const RestrictTable &t, int sign);
+void prolong_add_f32(hipStream_t s, int N, const float *Uc, int M, const float *Uf_in, float *Uf_out, const ProlongTable &t);
 void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n);
 void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n);
 void refine_residual(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, double *err_out);
@@ -226,7 +228,7 @@ void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2
 void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                        double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
                        const RestrictTable *rt, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
-                       const RowWindow *fc_w = nullptr, double *out_wide = nullptr);
+                       const RowWindow *fc_w = nullptr, double *out_wide = nullptr, float *D_out = nullptr, int d_sign = -1);
 // coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
 constexpr int TAIL_MAX_LEVELS = 6;
 constexpr int TAIL_MAX_NODES = 48;

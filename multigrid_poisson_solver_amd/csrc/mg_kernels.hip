@@ -229,17 +229,18 @@ __global__ __launch_bounds__(256) void k_finish_batch(const NormBatch b)
 // ---------------------------------------------------------------- restriction
 // src/MG_solver_CPU.cpp:656-678 with the 1-D tables built on the host from the
 // reference's floor/fmod expressions (:661-666); rim of the coarse grid is 0 (:651)
-__global__ __launch_bounds__(TB) void k_restrict(int N, const double *__restrict__ Uf, int M,
-                                                 double *__restrict__ Uc, const int *__restrict__ lo,
-                                                 const double *__restrict__ w, int sign)
+// T = field type (double; float for the operator-by-operator path of the mixed-precision mode)
+template <typename T>
+__global__ __launch_bounds__(TB) void k_restrict(int N, const T *__restrict__ Uf, int M, T *__restrict__ Uc,
+                                                 const int *__restrict__ lo, const T *__restrict__ w, int sign)
 {
     const int cc = blockIdx.x * TB + threadIdx.x;
     const int rc = blockIdx.y;
     if (cc >= M) return;
-    double v = 0.0;
+    T v = 0.0;
     if (!rim(rc, cc, M)) {
-        const double a = w[cc], b = 1.0 - a;
-        const double c = w[rc], d = 1.0 - c;
+        const T a = w[cc], b = T(1.0) - a;
+        const T c = w[rc], d = T(1.0) - c;
         const size_t f = (size_t)lo[cc] + (size_t)lo[rc] * N;
         v = b * d * Uf[f] + a * d * Uf[f + 1] + c * b * Uf[f + N] + a * c * Uf[f + N + 1];
         if (sign < 0) v = -v;
@@ -251,13 +252,12 @@ __global__ __launch_bounds__(TB) void k_restrict(int N, const double *__restrict
 // src/MG_solver_CPU.cpp:688-700 turned into a gather over fine points: the owning
 // coarse cell and the four 1-D weight factors come from host tables that replay the
 // reference's ceil() ranges and last-row/column rules (:697-718).
-template <bool ADD>
-__global__ __launch_bounds__(TB) void k_prolong(int N, const double *__restrict__ Uc, int M,
-                                                const double *__restrict__ Uf_in, double *__restrict__ Uf_out,
-                                                const int *__restrict__ orow, const int *__restrict__ ocol,
-                                                const double *__restrict__ row_hi, const double *__restrict__ row_lo,
-                                                const double *__restrict__ col_hi, const double *__restrict__ col_lo,
-                                                double c_dx)
+template <bool ADD, typename T>
+__global__ __launch_bounds__(TB) void k_prolong(int N, const T *__restrict__ Uc, int M, const T *__restrict__ Uf_in,
+                                                T *__restrict__ Uf_out, const int *__restrict__ orow,
+                                                const int *__restrict__ ocol, const T *__restrict__ row_hi,
+                                                const T *__restrict__ row_lo, const T *__restrict__ col_hi,
+                                                const T *__restrict__ col_lo, T c_dx)
 {
     const int l = blockIdx.x * TB + threadIdx.x;
     const int kf = blockIdx.y;
@@ -269,9 +269,9 @@ __global__ __launch_bounds__(TB) void k_prolong(int N, const double *__restrict_
         return;
     }
     const size_t p = (size_t)i * N + j;
-    const double c1 = Uc[p], c2 = Uc[p + 1], c3 = Uc[p + N], c4 = Uc[p + N + 1];
-    const double xh = col_hi[l], xl = col_lo[l], yh = row_hi[kf], yl = row_lo[kf];
-    const double v = ((c1 * xh + c2 * xl) * yh + (c3 * xh + c4 * xl) * yl) / c_dx / c_dx;
+    const T c1 = Uc[p], c2 = Uc[p + 1], c3 = Uc[p + N], c4 = Uc[p + N + 1];
+    const T xh = col_hi[l], xl = col_lo[l], yh = row_hi[kf], yl = row_lo[kf];
+    const T v = ((c1 * xh + c2 * xl) * yh + (c3 * xh + c4 * xl) * yl) / c_dx / c_dx;
     Uf_out[q] = ADD ? Uf_in[q] + v : v;   // doGridAddition :569: U1 = U1 + U2
 }
 
@@ -581,18 +581,29 @@ void smoothing_error(hipStream_t s, int N, double inv, const double *U, const do
 
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign)
 {
-    hipLaunchKernelGGL(k_restrict, dim3((M + TB - 1) / TB, M), dim3(TB), 0, s, N, Uf, M, Uc, t.lo, t.w, sign);
+    hipLaunchKernelGGL(k_restrict<double>, dim3((M + TB - 1) / TB, M), dim3(TB), 0, s, N, Uf, M, Uc, t.lo, t.w, sign);
+}
+void restrict_gather_f32(hipStream_t s, int N, const float *Uf, int M, float *Uc, const RestrictTable &t, int sign)
+{
+    hipLaunchKernelGGL(k_restrict<float>, dim3((M + TB - 1) / TB, M), dim3(TB), 0, s, N, Uf, M, Uc, t.lo, t.w_f, sign);
 }
 
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t)
 {
     const dim3 g((M + TB - 1) / TB, M);
     if (Uf_in)
-        hipLaunchKernelGGL(k_prolong<true>, g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
+        hipLaunchKernelGGL((k_prolong<true, double>), g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
                            t.row_hi, t.row_lo, t.col_hi, t.col_lo, t.c_dx);
     else
-        hipLaunchKernelGGL(k_prolong<false>, g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
+        hipLaunchKernelGGL((k_prolong<false, double>), g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
                            t.row_hi, t.row_lo, t.col_hi, t.col_lo, t.c_dx);
+}
+// U_out = U_in + P(U_c) on fp32 fields (weights rounded from the fp64 tables, fp32 divisions)
+void prolong_add_f32(hipStream_t s, int N, const float *Uc, int M, const float *Uf_in, float *Uf_out, const ProlongTable &t)
+{
+    const dim3 g((M + TB - 1) / TB, M);
+    hipLaunchKernelGGL((k_prolong<true, float>), g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
+                       t.row_hi_f, t.row_lo_f, t.col_hi_f, t.col_lo_f, (float)t.c_dx);
 }
 
 void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n)

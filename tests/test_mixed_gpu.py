@@ -38,7 +38,7 @@ def test_fused_nodes_fp32_vs_numpy(mg, N, step):
         assert err == pytest.approx(e, rel=1e-12)
 
 
-@pytest.mark.parametrize("kind,N,n_min", [("V", 256, 8), ("W", 128, 8), ("V", 1024, 8), ("V", 512, 32)])
+@pytest.mark.parametrize("kind,N,n_min", [("V", 256, 8), ("W", 128, 8), ("V", 1024, 8), ("V", 512, 32), ("V", 724, 8), ("W", 362, 8)])
 def test_mixed_cycle_vs_numpy_and_fp64(mg, oracle, tmp_path, kind, N, n_min):
     path = str(tmp_path / "c.txt")
     (mg.write_vcycle_file if kind == "V" else mg.write_wcycle_file)(path, N, n_min, 3, 1e-7)
@@ -64,6 +64,28 @@ def test_mixed_cycle_vs_numpy_and_fp64(mg, oracle, tmp_path, kind, N, n_min):
     assert np.abs(got["U"] - want["U"]).max() <= 2e-5 * scale
     assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-3)
     plan.close()
+
+
+@pytest.mark.parametrize("N", [181, 90])
+def test_fp32_nodes_on_odd_and_non_fusable_sizes(mg, N):
+    """Sizes the fused transfer stages do not cover (odd N; the hierarchy 724, 362, 181, 90, 45 of the
+    weak-scaling grids) run operator by operator in fp32: same numpy restatement, bit for bit."""
+    M = N // 2
+    rng = np.random.default_rng(N)
+    F = (rng.random((N, N)) - 0.5).astype(np.float32)
+    Fd, Uo, Fc = mg.DeviceGrid32.from_host(F), mg.DeviceGrid32((N, N)), mg.DeviceGrid32((M, M))
+    err = mg.smooth_restrict_f32(N, 1.0, Uo, Fd, 3, M, Fc, want_error=True)
+    U, e = o32.smooth(np.zeros((N, N), dtype=np.float32), F, 3, 1.0)
+    assert bits32(Uo.to_host(), U)
+    assert err == pytest.approx(e, rel=1e-12)
+    assert bits32(Fc.to_host(), o32.restrict_neg_residual(mg, U, F, 1.0, M))
+    Uc = (rng.random((M, M)) - 0.5).astype(np.float32)
+    Uf = rng.random((N, N)).astype(np.float32)
+    out = mg.DeviceGrid32((N, N))
+    err = mg.prolong_smooth_f32(M, mg.DeviceGrid32.from_host(Uc), N, 1.0, mg.DeviceGrid32.from_host(Uf), out, Fd, 3, want_error=True)
+    want, e = o32.smooth(o32.prolong_add(mg, Uc, Uf), F, 3, 1.0)
+    assert bits32(out.to_host(), want)
+    assert err == pytest.approx(e, rel=1e-12)
 
 
 def test_mixed_mode_refuses_unsupported_shapes(mg, tmp_path):
