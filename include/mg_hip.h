@@ -113,7 +113,8 @@ void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double 
                        double *F, int step, double *error_dev);
 /* mixed-precision mode (README.md:269-270 of the reference: "single
  * precision" GPU kernels): the two fused nodes with every array and every arithmetic operation
- * in fp32 (norms in fp64).  Zero start only; 1..4 steps; even N; nested coarse size. */
+ * in fp32 (norms in fp64).  Zero start only for the "-1" node; 1..4 steps.  Even N with a nested
+ * coarse size runs as ONE launch, anything else operator by operator (same results). */
 void   mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, float *F, int step,
                               double *error_dev, int M, float *F_c);
 void   mg_prolong_smooth_f32(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out,
