@@ -1,5 +1,6 @@
 """End-to-end parity of the cycle-file driver (libmgpoisson.so: mg_cycle_*) with the CPU
 oracle driver and the golden outputs of the reference program, on a real MI355X."""
+import ctypes as C
 import os
 import re
 import shutil
@@ -202,3 +203,29 @@ def test_reference_main_drives_the_engine(mg, golden_reports, cycle_dir, tmp_pat
     assert reports_match(body, golden_reports[name])
     if name == "test.txt":
         assert (tmp_path / "Sol_CPU_test.txt").read_text() == open(os.path.join(GOLDEN, "Sol_CPU_test.txt.csv")).read()
+
+
+@pytest.mark.parametrize("kind", ["V", "W"])
+def test_headline_size_cycles_vs_oracle(mg, oracle, tmp_path, kind):
+    """BASELINE.json's headline size, N = 8192^2 (configs[1] shape at the bench size, configs[2]: the
+    W-cycle recursion down to N = 8 with its 512 coarse solves): the fused driver against the oracle's
+    run of the same file -- the final U through the 128-bit checksum (computed on the device, so the
+    512 MiB array never crosses PCIe), every smoothing error, the analytic error."""
+    import _synth
+    N = 8192
+    path = str(tmp_path / f"{kind}{N}.txt")
+    (mg.write_vcycle_file if kind == "V" else mg.write_wcycle_file)(path, N, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path, want_report=False)
+    assert want["status"] == 0
+    want_sum = _synth.checksum(want["U"])
+    plan = mg.CyclePlan(path, fused=True, report=False)
+    got = plan.execute()
+    assert got["status"] == 0
+    out = (C.c_uint64 * 2)()
+    mg.lib().mg_checksum(got["U_ptr"], N * N, out)
+    assert (int(out[0]), int(out[1])) == want_sum, f"{kind}-cycle at N = {N}: final U differs from the oracle's"
+    assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+    assert len(got["records"]) == len(want["records"])
+    for g, w in zip(got["records"], want["records"]):
+        assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    plan.close()

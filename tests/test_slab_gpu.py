@@ -74,14 +74,15 @@ def test_virtual_slabs_on_the_weak_scaling_size_family(mg, oracle, tmp_path, R):
     single.close()
 
 
-def test_virtual_slabs_match_single_gpu_driver_at_4096(mg, tmp_path):
-    """8 slabs of a 4096^2 V-cycle against the single-GPU driver (itself pinned to the oracle)."""
-    N = 4096
-    path = str(tmp_path / "V4096.txt")
+@pytest.mark.parametrize("N,mixed", [(4096, False), (8192, False), (8192, True)])
+def test_virtual_slabs_match_single_gpu_driver_at_full_size(mg, tmp_path, N, mixed):
+    """8 slabs of a 4096^2 / 8192^2 V-cycle (fp64 and fp32 fields) against the single-GPU driver
+    (itself pinned to the oracle at these sizes, tests/test_cycle_gpu.py)."""
+    path = str(tmp_path / f"V{N}.txt")
     mg.write_vcycle_file(path, N, 8, 3, 1e-7)
-    single = mg.CyclePlan(path, fused=True, report=False)
+    single = mg.CyclePlan(path, fused=True, report=False, mixed=mixed)
     ref = single.execute(fetch_U=True)
-    plan = mg.SlabPlan(path, 8, -1, 512)
+    plan = mg.SlabPlan(path, 8, -1, 1024 if N == 8192 else 512, mixed=mixed)
     got = plan.execute()
     assert_bits(plan.gather_U(N), ref["U"], "8 slabs vs 1 GPU", zero_sign=True)
     assert got["mg_error"] == pytest.approx(ref["mg_error"], rel=1e-10)
