@@ -290,9 +290,24 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     for (int i = 0; i < a.n_nodes; ++i) {
         const TailNode nd = a.nodes[i];
         if (a.trace && threadIdx.x == 0 && i > 0) a.trace[1 + i] = wall_clock64();
+        // A wave none of whose threads owns a point of this node's level (N = 16: 12 of the 16 waves) only
+        // keeps the barrier count: the four waves of a SIMD issue in turn, so every instruction an idle wave
+        // runs through delays the wave next to it that has the work.
+        // (readfirstlane: the compiler must see a wave-uniform value, or every variable updated under the
+        // branch -- cur, swapped, parity -- turns into a per-lane register and the loops below into masked ones)
+        const int wave_first = __builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63;
         if (nd.type == -1) {
             // memset(U,0) :256, doSmoothing :259, getResidual :268, sign flip :277-280, doRestriction :287
-            const int N = a.N[cur], F = F_of(cur);
+            const int N = a.N[cur];
+            if (wave_first >= N * N) {
+                if ((threadIdx.x & 63) == 0) slots[parity][threadIdx.x >> 6] = 0.0;
+                for (int b = 0; b < nd.steps + 2; ++b) __syncthreads();
+                if ((nd.steps - 1) & 1) swapped ^= 1u << cur;
+                parity ^= 1;
+                ++cur;
+                continue;
+            }
+            const int F = F_of(cur);
             const Points P = map_points(N);
             const real_t dx2 = a.dx2[cur], inv = a.inv[cur];
             real_t v[PT], f[PT], h2f[PT];
@@ -350,6 +365,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             __syncthreads();
         } else {  // 1: doProlongation :354, doGridAddition :368, doSmoothing :416
             const int Nc = a.N[cur], fine = cur - 1, N = a.N[fine];
+            if (wave_first >= N * N) {
+                if ((threadIdx.x & 63) == 0) slots[parity][threadIdx.x >> 6] = 0.0;
+                for (int b = 0; b < nd.steps + 2; ++b) __syncthreads();
+                if (nd.steps & 1) swapped ^= 1u << fine;
+                parity ^= 1;
+                --cur;
+                continue;
+            }
             const int uc = U_of(cur), F = F_of(fine);
             const int rt = real_tab(a, fine) + Nc, it = int_tab(a, fine) + Nc;  // past w[M] / lo[M]
             const real_t c_dx = a.c_dx[fine], c_rcp = real_t(1.0) / c_dx, dx2 = a.dx2[fine], inv = a.inv[fine];
