@@ -260,6 +260,10 @@ mg_slab_plan *mg_slab_load(const char *path, int nranks, int rank, int collapse_
 /* the same with flags: MG_CYCLE_MIXED = the whole cycle on fp32 slabs (half the HBM and xGMI bytes;
  * source rounded once, exact solver in fp64, mg_slab_gather_U widens), BASELINE.json configs[4] */
 mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int collapse_N, int flags);
+/* MG_CYCLE_MIXED slab plans: like mg_cycle_set_refinement / mg_cycle_refinement_errors.  Each extra cycle
+ * costs one ghost exchange of the fp64 iterate and one of the new fp32 source on the finest level. */
+int  mg_slab_set_refinement(mg_slab_plan *plan, int cycles);
+int  mg_slab_refinement_errors(mg_slab_plan *plan, double *out, int cap);
 /* one run of the reference's timed window; U_dev is NULL (use mg_slab_gather_U) */
 int  mg_slab_execute(mg_slab_plan *plan, mg_cycle_result *out);
 /* like mg_cycle_enqueue / mg_cycle_collect */

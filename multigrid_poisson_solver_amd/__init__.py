@@ -80,6 +80,7 @@ ABI = {
     "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_rank": (_i, []),
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
+    "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
@@ -576,11 +577,15 @@ def comm_unique_id():
 class SlabPlan:
     """The cycle-file driver on a 1-D row-slab decomposition (mg_slab_*)."""
 
-    def __init__(self, path, nranks, rank=-1, collapse_N=512, mixed=False):
+    def __init__(self, path, nranks, rank=-1, collapse_N=512, mixed=False, refinement=1):
         self._plan = lib().mg_slab_load_flags(os.fsencode(path), nranks, rank, collapse_N, MG_CYCLE_MIXED if mixed else 0)
         _check()
         if not self._plan:
             raise MGError(f"cannot load cycle file {path} in row-slab mode")
+        self.refinement = refinement
+        if refinement != 1:
+            _lib.mg_slab_set_refinement(self._plan, refinement)
+            _check()
 
     def enqueue(self):
         status = _lib.mg_slab_enqueue(self._plan)
@@ -594,9 +599,14 @@ class SlabPlan:
         res = CycleResult()
         status = (_lib.mg_slab_collect if _collect_only else _lib.mg_slab_execute)(self._plan, C.byref(res))
         _check()
-        return dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
-                    records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
-                             for i in range(res.n_records)])
+        out = dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
+                   records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
+                            for i in range(res.n_records)])
+        if self.refinement > 1:
+            e = np.zeros(self.refinement - 1)
+            n = _lib.mg_slab_refinement_errors(self._plan, e.ctypes.data, e.size)
+            out["refinement_errors"] = e[:n].tolist()
+        return out
 
     def want_error(self, on):
         _lib.mg_slab_want_error(self._plan, 1 if on else 0)

@@ -213,6 +213,8 @@ void convert_to_f32(hipStream_t s, float *dst, const double *src, size_t n);
 void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n);
 void refine_residual(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, double *err_out);
 void add_widened(hipStream_t s, double *U, const float *e, size_t n);
+void refine_residual_rows(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, const RowWindow &w,
+                          double *out_raw);
 void add(hipStream_t s, size_t n, double *a, const double *b);
 void negate(hipStream_t s, size_t n, double *a);
 void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y);

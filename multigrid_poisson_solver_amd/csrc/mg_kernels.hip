@@ -179,6 +179,33 @@ __global__ __launch_bounds__(TB) void k_refine_residual(int N, double inv, const
     if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// the same on a row window (slab mode): rows [own_lo, own_hi) of arrays whose first row is `base`; the
+// halo rows own_lo - 1 and own_hi of U must be there; the norm is left as this slab's raw sum
+__global__ __launch_bounds__(TB) void k_refine_residual_rows(int N, double inv, const double *__restrict__ U,
+                                                             const double *__restrict__ F, float *__restrict__ src, int base,
+                                                             int own_lo, int own_hi, double *__restrict__ part)
+{
+    const int c = blockIdx.x * TB + threadIdx.x;
+    const int r0 = own_lo + blockIdx.y * ROWS_PB;
+    double acc = 0.0;
+    if (c < N) {
+#pragma unroll
+        for (int k = 0; k < ROWS_PB; ++k) {
+            const int r = r0 + k;
+            if (r >= own_hi) break;
+            const size_t p = (size_t)(r - base) * N + c;
+            double v = 0.0;
+            if (!rim(r, c, N)) {
+                v = inv * star_minus4(U, p, N) - F[p];
+                if (((r + c) & 1) == 0) acc += fabs(v);
+            }
+            src[p] = (float)(-v);
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
 // U += (double)e: the fp64 correction step of the refinement
 __global__ __launch_bounds__(TB) void k_add_widened(double *__restrict__ U, const float *__restrict__ e, size_t n)
 {
@@ -622,6 +649,20 @@ void refine_residual(hipStream_t s, int N, double inv, const double *U, const do
     double *part = partials(np);
     hipLaunchKernelGGL(k_refine_residual, g, dim3(TB), 0, s, N, inv, U, F, src, part);
     finish(s, part, np, FIN_SMOOTH_ERR, N, err_out);
+}
+void refine_residual_rows(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, const RowWindow &w,
+                          double *out_raw)
+{
+    const int own = w.own_hi - w.own_lo;
+    if (own <= 0) {
+        (void)hipMemsetAsync(out_raw, 0, sizeof(double), s);
+        return;
+    }
+    const dim3 g((N + TB - 1) / TB, (own + ROWS_PB - 1) / ROWS_PB);
+    const size_t np = (size_t)g.x * g.y;
+    double *part = partials(np);
+    hipLaunchKernelGGL(k_refine_residual_rows, g, dim3(TB), 0, s, N, inv, U, F, src, w.base, w.own_lo, w.own_hi, part);
+    finish(s, part, np, FIN_RAW, N, out_raw);
 }
 void add_widened(hipStream_t s, double *U, const float *e, size_t n)
 {

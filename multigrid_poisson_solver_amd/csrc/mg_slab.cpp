@@ -128,7 +128,14 @@ struct mg_slab_plan {
     int want_error = 1;   // evaluate the analytic error after the window (outside the timing)
     bool mixed = false;   // MG_CYCLE_MIXED: fp32 fields (the double* members then only carry addresses)
     size_t elem = sizeof(double);
-    std::vector<double *> U64;   // mixed: per local rank, the finest window widened to fp64 (result / error)
+    std::vector<double *> U64;   // mixed: per local rank, the finest window in fp64 (result / error / refinement iterate)
+    std::vector<double *> F64;   // mixed: per local rank, the fp64 source rows of the finest window
+    int refinements = 1;         // mixed: fp32 cycles per window, joined by an fp64 residual and correction
+    bool U64_current = false;    // U64 holds the result of the last window (refinement keeps it up to date)
+    bool F32_stale = false;      // the finest fp32 F holds a residual, not the rounded source
+    double *refine_raw = nullptr;  // [refinements-1][n_local] raw residual norms of the intermediate iterates
+    double *refine_all = nullptr;  // real mode: all-gather target
+    std::vector<double> refine_err;
     // per hierarchy index and GLOBAL rank: the rows a `1` node updates = owned rows + the halo rows the
     // next finer level's `1` node reads through the prolongation (distributed levels only)
     std::vector<std::vector<std::pair<int, int>>> ext;
@@ -196,6 +203,9 @@ enum Which { ARR_U, ARR_F };
 struct GhostItem {
     Level *lv;
     Which which;
+    // other arrays with the level's window geometry (the fp64 iterate of the refinement): one per local rank
+    const std::vector<double *> *raw = nullptr;
+    size_t raw_elem = 0;
 };
 void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group);
 
@@ -211,8 +221,12 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
     for (const GhostItem &it : items) {
         Level &lv = *it.lv;
         const int N = lv.N;
-        const size_t cnt = (size_t)GHOST * N * p->elem;  // bytes
-        auto arr = [&](size_t i) { return it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F; };
+        const size_t elem = it.raw ? it.raw_elem : p->elem;
+        const size_t cnt = (size_t)GHOST * N * elem;  // bytes
+        auto arr = [&](size_t i) { return it.raw ? (*it.raw)[i] : (it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F); };
+        auto row_at = [&](const mg_slab_plan *, double *a, const RowWindow &w, int n, int y) {
+            return (void *)((char *)a + (size_t)(y - w.base) * n * elem);
+        };
         if (!p->real) {
             for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
                 const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
@@ -616,13 +630,16 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
             fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(top.loc[i].F, w, top.N, lo));
             continue;
         }
-        // mixed: the fp64 source rows go through the widened-result buffer and are rounded once
-        double *tmp = (double *)p->pool.get((size_t)w.rows * top.N * sizeof(double));
-        if (!tmp) { mg_slab_destroy(p); return nullptr; }
-        p->U64.push_back(tmp);
+        // mixed: the fp64 source rows are kept (the refinement forms its residual against them) and rounded
+        // once into the fp32 field; a second fp64 window holds the widened result / the refinement's iterate
+        double *f64 = (double *)p->pool.get((size_t)w.rows * top.N * sizeof(double));
+        double *u64 = (double *)p->pool.get((size_t)w.rows * top.N * sizeof(double));
+        if (!f64 || !u64) { mg_slab_destroy(p); return nullptr; }
+        p->F64.push_back(f64);
+        p->U64.push_back(u64);
         const size_t n = (size_t)(hi - lo) * top.N;
-        fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, tmp);
-        k::convert_to_f32(ctx().stream, (float *)row_at(p, top.loc[i].F, w, top.N, lo), tmp, n);
+        fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(f64, w, top.N, lo));
+        k::convert_to_f32(ctx().stream, (float *)row_at(p, top.loc[i].F, w, top.N, lo), row_ptr(f64, w, top.N, lo), n);
     }
     p->levels.push_back(top);
     (void)hipEventCreate(&p->ev0);
@@ -636,17 +653,55 @@ int mg_slab_enqueue(mg_slab_plan *p)
 {
     if (!require_ready("mg_slab_enqueue") || !p) return 1;
     Context &c = ctx();
-    while (p->levels.size() > 1) {
-        free_level(p, p->levels.back());
-        p->levels.pop_back();
-    }
-    p->records.clear();
-    p->rec_final.clear();
-    p->status = 0;
-    c.active_pool = &p->pool;
-    (void)hipMemsetAsync(p->raw_dev, 0, (p->max_rec + 1) * p->local.size() * sizeof(double), c.stream);
     (void)hipEventRecord(p->ev0, c.stream);
-    run(p);
+    p->status = 0;
+    p->U64_current = false;
+    const int outer = p->mixed ? p->refinements : 1;
+    for (int it = 0; it < outer && p->status == 0; ++it) {
+        while (p->levels.size() > 1) {
+            free_level(p, p->levels.back());
+            p->levels.pop_back();
+        }
+        p->records.clear();  // those of the last cycle are reported
+        p->rec_final.clear();
+        c.active_pool = &p->pool;
+        (void)hipMemsetAsync(p->raw_dev, 0, (p->max_rec + 1) * p->local.size() * sizeof(double), c.stream);
+        Level &top = p->levels[0];
+        if (it > 0 || p->F32_stale) {
+            // mixed-precision refinement (mg_cycle_set_refinement on slabs): the fp32 source of this cycle is
+            // the fp64 residual of the fp64 iterate (one halo row of it comes from the neighbours), rounded;
+            // its own halo rows are exchanged like any F.  A new window first restores the rounded source.
+            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_U, &p->U64, sizeof(double)}});
+            for (size_t i = 0; i < p->local.size(); ++i) {
+                const RowWindow w = window_of(top.part, p->local[i]);
+                if (it > 0) {
+                    const double dx = p->L / (double)(top.N - 1);
+                    k::refine_residual_rows(c.stream, top.N, 1.0 / (dx * dx), p->U64[i], p->F64[i], (float *)top.loc[i].F, w,
+                                            p->refine_raw + (size_t)(it - 1) * p->local.size() + i);
+                } else {
+                    const int lo = std::max(0, w.base), hi = std::min(top.N, w.base + w.rows);
+                    k::convert_to_f32(c.stream, (float *)row_at(p, top.loc[i].F, w, top.N, lo), row_ptr(p->F64[i], w, top.N, lo),
+                                      (size_t)(hi - lo) * top.N);
+                }
+            }
+            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_F}});
+            p->F32_stale = it > 0;
+        }
+        run(p);
+        if (p->mixed && outer > 1 && p->status == 0) {
+            // fp64 correction on the owned rows: U64 = (double)e on the first cycle, U64 += (double)e afterwards
+            Level &top = p->levels[0];  // (run() grows the level vector: the reference above is gone)
+            for (size_t i = 0; i < p->local.size(); ++i) {
+                const RowWindow w = window_of(top.part, p->local[i]);
+                const size_t n = (size_t)(w.own_hi - w.own_lo) * top.N;
+                double *u64 = row_ptr(p->U64[i], w, top.N, w.own_lo);
+                const float *e = (const float *)row_at(p, top.loc[i].U, w, top.N, w.own_lo);
+                if (it == 0) k::convert_to_f64(c.stream, u64, e, n);
+                else k::add_widened(c.stream, u64, e, n);
+            }
+            p->U64_current = true;
+        }
+    }
     (void)hipEventRecord(p->ev1, c.stream);
     c.active_pool = nullptr;
     return p->status;
@@ -682,8 +737,8 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
     for (size_t i = 0; i < nloc && p->want_error; ++i) {
         const RowWindow w = window_of(top.part, p->local[i]);
         const double *U = top.loc[i].U;
-        if (p->mixed) {  // widen the whole window (exact); the kernel reads the owned rows
-            k::convert_to_f64(c.stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
+        if (p->mixed) {  // widen the whole window (exact) unless the refinement kept U64 up to date
+            if (!p->U64_current) k::convert_to_f64(c.stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
             U = p->U64[i];
         }
         k::analytic_error_rows(c.stream, top.N, p->L, U, w, p->min_x, p->min_y, raw_slot(p, p->max_rec, i));
@@ -711,6 +766,27 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
         e = e / rec.N / rec.N;
         rec.error = e;
     }
+    p->refine_err.clear();
+    if (p->mixed && p->refinements > 1 && p->refine_raw) {
+        const size_t k = (size_t)p->refinements - 1;
+        std::vector<double> rr(k * (size_t)p->nranks, 0.0);  // [iterate][global rank]
+        if (p->real) {
+            comm_allgather(p->refine_raw, p->refine_all, k);
+            std::vector<double> tmp(k * (size_t)p->nranks);
+            mg_download(tmp.data(), p->refine_all, tmp.size());
+            for (int r = 0; r < p->nranks; ++r)
+                for (size_t j = 0; j < k; ++j) rr[j * (size_t)p->nranks + r] = tmp[(size_t)r * k + j];
+        } else {
+            mg_download(rr.data(), p->refine_raw, rr.size());
+        }
+        for (size_t j = 0; j < k; ++j) {
+            double sum = 0.0;
+            for (int r = 0; r < p->nranks; ++r) sum += rr[j * (size_t)p->nranks + r];
+            double e = sum + sum;  // :621-622
+            e = e / top.N / top.N;
+            p->refine_err.push_back(e);
+        }
+    }
     double a = 0.0;
     for (int r = 0; r < p->nranks; ++r) a += raw[p->max_rec * (size_t)p->nranks + r];
 
@@ -735,12 +811,39 @@ int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
         const RowWindow w = window_of(top.part, p->local[i]);
         double *U = top.loc[i].U;
         if (p->mixed) {
-            k::convert_to_f64(ctx().stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
+            if (!p->U64_current) k::convert_to_f64(ctx().stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
             U = p->U64[i];
         }
         mg_download(host_full + (size_t)w.own_lo * top.N, row_ptr(U, w, top.N, w.own_lo), (size_t)(w.own_hi - w.own_lo) * top.N);
     }
     return 0;
+}
+
+// mixed-precision slabs: `cycles` fp32 runs of the file per window joined by the fp64 residual of the fp64
+// iterate and an fp64 correction (see mg_cycle_set_refinement); one more one-row... GHOST-row exchange of
+// the fp64 iterate and one of the new fp32 source per extra cycle
+int mg_slab_set_refinement(mg_slab_plan *p, int cycles)
+{
+    if (!require_ready("mg_slab_set_refinement") || !p) return 1;
+    if (!p->mixed || cycles < 1 || cycles > 64) {
+        fail(MG_ERR_ARG, "mg_slab_set_refinement: needs a MG_CYCLE_MIXED plan and 1..64 cycles (got %d)", cycles);
+        return 1;
+    }
+    if (!p->refine_raw) {
+        p->refine_raw = (double *)p->pool.get(64 * p->local.size() * sizeof(double));
+        if (p->real) p->refine_all = (double *)p->pool.get(64 * (size_t)p->nranks * sizeof(double));
+        if (!p->refine_raw) return 1;
+    }
+    p->refinements = cycles;
+    return 0;
+}
+
+int mg_slab_refinement_errors(mg_slab_plan *p, double *out, int cap)
+{
+    if (!p || !out) return 0;
+    int n = 0;
+    for (; n < (int)p->refine_err.size() && n < cap; ++n) out[n] = p->refine_err[(size_t)n];
+    return n;
 }
 
 void mg_slab_want_error(mg_slab_plan *p, int on)
@@ -757,6 +860,9 @@ void mg_slab_destroy(mg_slab_plan *p)
     if (p->raw_dev) p->pool.put(p->raw_dev);
     if (p->all_dev) p->pool.put(p->all_dev);
     for (double *b : p->U64) p->pool.put(b);
+    for (double *b : p->F64) p->pool.put(b);
+    if (p->refine_raw) p->pool.put(p->refine_raw);
+    if (p->refine_all) p->pool.put(p->refine_all);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     p->pool.trim();

@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     cycle_path, want_path, collapse = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    mixed = len(sys.argv) > 4 and sys.argv[4] == "mixed"
+    mixed = len(sys.argv) > 4 and sys.argv[4].startswith("mixed")
+    cycles = int(sys.argv[4][5:]) if mixed and len(sys.argv[4]) > 5 else 1   # "mixed3": 3 refinement cycles
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import multigrid_poisson_solver_amd as mg
@@ -36,7 +37,7 @@ def main():
     mg.comm_init_host(rank, world, exchange, allgather)
     want = np.load(want_path)
     N = int(want["N"])
-    plan = mg.SlabPlan(cycle_path, world, rank, collapse, mixed=mixed)
+    plan = mg.SlabPlan(cycle_path, world, rank, collapse, mixed=mixed, refinement=cycles)
     for run in range(2):  # the second window re-runs on the state the first one left behind
         res = plan.execute()
         assert res["status"] == 0, res

@@ -181,3 +181,22 @@ def test_mixed_slabs_virtual_ranks_vs_numpy(mg, oracle, tmp_path, R, collapse):
     single = mg.CyclePlan(path, fused=True, mixed=True).execute()
     assert got["mg_error"] == pytest.approx(single["mg_error"], rel=1e-10)
     plan.close()
+
+
+@pytest.mark.parametrize("R,N,collapse,cycles", [(3, 1024, 128, 3), (8, 2048, 256, 2)])
+def test_mixed_slab_refinement_matches_single_gpu(mg, tmp_path, R, N, collapse, cycles):
+    """fp64 residual + correction between fp32 cycles on row slabs (one ghost exchange of the fp64
+    iterate and one of the new fp32 source per extra cycle): the iterate and the residual norms of
+    the single-GPU refinement (itself pinned to the numpy restatement), bit for bit / to 1e-12."""
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    one = mg.CyclePlan(path, fused=True, mixed=True, refinement=cycles)
+    want = one.execute(fetch_U=True)
+    plan = mg.SlabPlan(path, R, -1, collapse, mixed=True, refinement=cycles)
+    for _ in range(2):   # the second window has to restore the rounded source first
+        got = plan.execute()
+        assert got["status"] == 0 and want["status"] == 0
+        assert np.array_equal(plan.gather_U(N), want["U"])
+        assert got["refinement_errors"] == pytest.approx(want["refinement_errors"], rel=1e-12)
+        assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+    plan.close(); one.close()

@@ -122,7 +122,7 @@ def test_rccl_communicator_single_rank(mg):
 
 
 @pytest.mark.parametrize("world,N,collapse,mixed", [(2, 512, 64, False), (3, 1024, 128, False), (4, 1024, 256, False),
-                                                    (3, 1024, 128, True)])
+                                                    (3, 1024, 128, True), (2, 1024, 128, 3)])
 def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse, mixed):
     """The driver in RANK mode (one process per slab, as under RCCL) with the host-staged
     transport over gloo: `world` processes on this one GPU, every rank's owned rows bit-identical
@@ -133,7 +133,7 @@ def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse,
     path = str(tmp_path / "V.txt")
     mg.write_vcycle_file(path, N, 8, 3, 1e-7)
     if mixed:   # fp32 slabs: the single-GPU fp32 cycle (itself pinned to the numpy restatement) is the yardstick
-        one = mg.CyclePlan(path, fused=True, mixed=True)
+        one = mg.CyclePlan(path, fused=True, mixed=True, refinement=int(mixed))   # True -> 1 cycle, 3 -> refinement
         want = one.execute(fetch_U=True)
         one.close()
     else:
@@ -151,7 +151,7 @@ def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse,
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(here, "_slab_host_worker.py"), path, want_path, str(collapse)] + (["mixed"] if mixed else [])
+           os.path.join(here, "_slab_host_worker.py"), path, want_path, str(collapse)] + ([f"mixed{int(mixed)}"] if mixed else [])
     out = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert f"SLAB_HOST_TRANSPORT OK {world} {N} {collapse}" in out.stdout
