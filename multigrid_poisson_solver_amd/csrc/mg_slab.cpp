@@ -820,8 +820,8 @@ int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
 }
 
 // mixed-precision slabs: `cycles` fp32 runs of the file per window joined by the fp64 residual of the fp64
-// iterate and an fp64 correction (see mg_cycle_set_refinement); one more one-row... GHOST-row exchange of
-// the fp64 iterate and one of the new fp32 source per extra cycle
+// iterate and an fp64 correction (see mg_cycle_set_refinement); per extra cycle one ghost exchange of the
+// fp64 iterate and one of the new fp32 source, both on the finest level
 int mg_slab_set_refinement(mg_slab_plan *p, int cycles)
 {
     if (!require_ready("mg_slab_set_refinement") || !p) return 1;
