@@ -38,7 +38,7 @@ def test_fused_nodes_fp32_vs_numpy(mg, N, step):
         assert err == pytest.approx(e, rel=1e-12)
 
 
-@pytest.mark.parametrize("kind,N,n_min", [("V", 256, 8), ("W", 128, 8), ("V", 1024, 8), ("V", 512, 32), ("V", 724, 8), ("W", 362, 8)])
+@pytest.mark.parametrize("kind,N,n_min", [("V", 256, 8), ("W", 128, 8), ("V", 1024, 8), ("V", 512, 32), ("V", 724, 8), ("W", 362, 8), ("V", 704, 8)])
 def test_mixed_cycle_vs_numpy_and_fp64(mg, oracle, tmp_path, kind, N, n_min):
     path = str(tmp_path / "c.txt")
     (mg.write_vcycle_file if kind == "V" else mg.write_wcycle_file)(path, N, n_min, 3, 1e-7)
