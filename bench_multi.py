@@ -3,8 +3,8 @@ torch.distributed.run), 1-D row slabs, ghost rows over RCCL/xGMI.
 
 Weak scaling: the per-GPU share of the finest grid stays at the 8192^2 points the
 single-GPU metric is quoted on, so the grid is N_g x N_g with N_g ~ 8192*sqrt(gpus)
-(8192, 11584, 16384, 23168 for 1, 2, 4, 8 GPUs; multiples of 64 so that every distributed
-level keeps an even size).  `value` is the whole-job aggregate: lattice updates of one
+(8192, 11520, 16384, 23040 for 1, 2, 4, 8 GPUs: sizes m * 2^j with m <= 64, so that every level
+above the coarse-tail kernel keeps an even size).  `value` is the whole-job aggregate: lattice updates of one
 V(3,3)-cycle over ALL slabs divided by the slowest rank's time.
 
 torch is imported BEFORE the engine on purpose: libmgpoisson.so then binds to the HIP and RCCL
@@ -23,8 +23,20 @@ HBM_PEAK_GBS = 8000.0
 
 
 def grid_for(world, base=8192, mixed=False):
-    n = base * math.sqrt(world)
-    return int(round(n / 64.0)) * 64
+    """Weak scaling: ~base^2 points per GPU.  Among the sizes m * 2^j with m <= 64 (every level above the
+    coarse-tail kernel's N <= 64 is then even, so every node runs in its fused one-launch form) the one nearest
+    to base * sqrt(world): 8192, 11520, 16384, 23040 for 1, 2, 4, 8 GPUs."""
+    target = base * math.sqrt(world)
+    best = None
+    for m in range(33, 65):
+        j = max(0, round(math.log2(target / m)))
+        for jj in (j - 1, j, j + 1):
+            if jj < 1:
+                continue
+            n = m * 2 ** jj
+            if best is None or abs(n - target) < abs(best - target):
+                best = n
+    return int(best)
 
 
 def host_transport(mg, rank, world):

@@ -233,7 +233,7 @@ def test_headline_size_cycles_vs_oracle(mg, oracle, tmp_path, kind):
 
 @pytest.mark.parametrize("kind,N,n_min", [("V", 88, 8), ("V", 1448, 8), ("W", 176, 8), ("V", 104, 8), ("V", 256, 16), ("V", 120, 8)])
 def test_cycles_whose_coarsest_level_has_65_to_256_points(mg, oracle, tmp_path, kind, N, n_min):
-    """Hierarchies that do not end on an 8 x 8 grid (the weak-scaling grids 11584 and 23168 end on 11 x 11;
+    """Hierarchies that do not end on an 8 x 8 grid (the weak-scaling grids 11520 and 23040 end on 11 x 11;
     104 -> 13, 256 with N_min 16 -> 16, 120 -> 15): the coarse-tail kernel solves them with the
     one-wave LDS Gauss-Seidel; iterates, iteration count and everything downstream as the oracle's."""
     path = str(tmp_path / "c.txt")

@@ -42,7 +42,7 @@ def test_partition_properties():
     import multigrid_poisson_solver_amd as mg
     G = mg.slab_ghost_rows()
     assert G >= 6
-    for N, R, collapse in [(8192, 8, 1024), (23168, 8, 1024), (11584, 2, 1024), (1024, 3, 128), (16384, 4, 512)]:
+    for N, R, collapse in [(8192, 8, 1024), (23040, 8, 1024), (11520, 2, 1024), (23168, 8, 1024), (1024, 3, 128), (16384, 4, 512)]:
         levels = mg.slab_partition(N, 8, R, collapse)
         seen_collapsed = False
         for li, (n, collapsed, ranges) in enumerate(levels):

@@ -55,14 +55,14 @@ def test_virtual_slabs_wcycle_and_other_steps(mg, oracle, tmp_path, R):
     plan.close()
 
 
-@pytest.mark.parametrize("R", [2, 8])
-def test_virtual_slabs_on_the_weak_scaling_size_family(mg, oracle, tmp_path, R):
-    """bench.py --gpus 2/8 runs N = 11584 / 23168 = 2^k * 181: the hierarchy halves down to the odd
-    size 181 and on to 90, 45, 22, 11.  Same chain at 1/8 of the size: 1448 -> 724 distributed,
-    362 -> 181 -> 90 -> 45 -> 22 -> 11 collapsed (odd levels, non-nested transfers, coarse tail)."""
-    N = 1448
-    path = str(tmp_path / "V1448.txt")
-    assert mg.write_vcycle_file(path, N, 8, 3, 1e-7) == 8
+@pytest.mark.parametrize("R,N,levels", [(2, 1448, 8), (8, 1448, 8), (2, 1440, 8), (8, 1440, 8)])
+def test_virtual_slabs_on_the_weak_scaling_size_family(mg, oracle, tmp_path, R, N, levels):
+    """bench.py --gpus 2/8 runs N = 11520 / 23040 = 2^k * 45: every level above the coarse tail is even,
+    the tail runs 45 -> 22 -> 11 (one-wave LDS Gauss-Seidel on 11 x 11).  Same chain at 1/8 of the size
+    (1440), and the harder family 2^k * 181 (1448 -> 724 distributed, 362 -> 181 -> 90 -> 45 -> 22 -> 11
+    collapsed: an odd level above the tail, non-nested transfers)."""
+    path = str(tmp_path / f"V{N}.txt")
+    assert mg.write_vcycle_file(path, N, 8, 3, 1e-7) == levels
     want = oracle.run_cycle_file(path)
     plan = mg.SlabPlan(path, R, -1, 400)
     got = plan.execute()
