@@ -94,6 +94,7 @@ struct Local {  // one local rank's arrays of one level
 
 struct Level {
     int N = 0;
+    int hier = 0;             // index into the plan's hierarchy (sizes / parts / ext / depth)
     bool collapsed = false;   // whole grid replicated on every rank
     Partition part;           // distributed levels
     std::vector<Local> loc;   // per local rank (collapsed: full N x N arrays, distributed: windows)
@@ -139,6 +140,7 @@ struct mg_slab_plan {
     // per hierarchy index and GLOBAL rank: the rows a `1` node updates = owned rows + the halo rows the
     // next finer level's `1` node reads through the prolongation (distributed levels only)
     std::vector<std::vector<std::pair<int, int>>> ext;
+    std::vector<int> depth;      // per hierarchy index: ghost rows that actually travel (<= GHOST, what the level reads)
     bool poison = false;         // MG_SLAB_POISON: fresh level arrays are filled with NaN (tests)
 };
 
@@ -206,6 +208,7 @@ struct GhostItem {
     // other arrays with the level's window geometry (the fp64 iterate of the refinement): one per local rank
     const std::vector<double *> *raw = nullptr;
     size_t raw_elem = 0;
+    int depth = 0;  // rows per side; 0: the level's own depth (plan->depth)
 };
 void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group);
 
@@ -222,7 +225,9 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
         Level &lv = *it.lv;
         const int N = lv.N;
         const size_t elem = it.raw ? it.raw_elem : p->elem;
-        const size_t cnt = (size_t)GHOST * N * elem;  // bytes
+        // only the rows the level's launches read travel (the finest level: S+2 of the 12 halo rows)
+        const int G = it.depth > 0 ? it.depth : p->depth[(size_t)lv.hier];
+        const size_t cnt = (size_t)G * N * elem;  // bytes
         auto arr = [&](size_t i) { return it.raw ? (*it.raw)[i] : (it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F); };
         auto row_at = [&](const mg_slab_plan *, double *a, const RowWindow &w, int n, int y) {
             return (void *)((char *)a + (size_t)(y - w.base) * n * elem);
@@ -232,7 +237,7 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
                 const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
                 double *A = arr((size_t)r), *B = arr((size_t)r + 1);
                 // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
-                (void)hipMemcpyAsync(row_at(p, B, b, N, b.own_lo - GHOST), row_at(p, A, a, N, a.own_hi - GHOST), cnt,
+                (void)hipMemcpyAsync(row_at(p, B, b, N, b.own_lo - G), row_at(p, A, a, N, a.own_hi - G), cnt,
                                      hipMemcpyDeviceToDevice, c.stream);
                 (void)hipMemcpyAsync(row_at(p, A, a, N, a.own_hi), row_at(p, B, b, N, b.own_lo), cnt, hipMemcpyDeviceToDevice,
                                      c.stream);
@@ -243,12 +248,12 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
         const RowWindow w = window_of(lv.part, r);
         double *A = arr(0);
         if (r + 1 < R) {
-            comm_send(row_at(p, A, w, N, w.own_hi - GHOST), cnt, r + 1);
+            comm_send(row_at(p, A, w, N, w.own_hi - G), cnt, r + 1);
             comm_recv(row_at(p, A, w, N, w.own_hi), cnt, r + 1);
         }
         if (r > 0) {
             comm_send(row_at(p, A, w, N, w.own_lo), cnt, r - 1);
-            comm_recv(row_at(p, A, w, N, w.own_lo - GHOST), cnt, r - 1);
+            comm_recv(row_at(p, A, w, N, w.own_lo - G), cnt, r - 1);
         }
     }
     if (share) share_rows(p, *share, *share_part, true);
@@ -324,6 +329,7 @@ void run(mg_slab_plan *p)
             Level &cur = p->levels.back();
             Level nxt;
             nxt.N = M;
+            nxt.hier = hier;
             nxt.collapsed = p->level_collapsed[(size_t)hier];
             if (!nxt.collapsed) nxt.part = p->parts[(size_t)hier];
             alloc_level(p, nxt);
@@ -609,6 +615,16 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
                 p->ext[l][(size_t)r] = std::make_pair(lo, hi);
             }
         }
+        // ghost rows that travel per level: what its `1` node reads beyond the owned rows (its `-1` node reads H)
+        p->depth.assign(nl, GHOST);
+        for (size_t l = 0; l < nl && !p->level_collapsed[l]; ++l) {
+            int e = 0;
+            for (int r = 0; r < nranks; ++r) {
+                e = std::max(e, p->parts[l].lo[(size_t)r] - p->ext[l][(size_t)r].first);
+                e = std::max(e, p->ext[l][(size_t)r].second - p->parts[l].hi[(size_t)r]);
+            }
+            p->depth[l] = std::min(GHOST, e + H);
+        }
     }
     p->poison = getenv("MG_SLAB_POISON") != nullptr;
     size_t smoothing_nodes = 0;
@@ -671,7 +687,7 @@ int mg_slab_enqueue(mg_slab_plan *p)
             // mixed-precision refinement (mg_cycle_set_refinement on slabs): the fp32 source of this cycle is
             // the fp64 residual of the fp64 iterate (one halo row of it comes from the neighbours), rounded;
             // its own halo rows are exchanged like any F.  A new window first restores the rounded source.
-            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_U, &p->U64, sizeof(double)}});
+            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_U, &p->U64, sizeof(double), 1}});  // the 5-point star: one row
             for (size_t i = 0; i < p->local.size(); ++i) {
                 const RowWindow w = window_of(top.part, p->local[i]);
                 if (it > 0) {
