@@ -95,7 +95,7 @@ def run(args, rank, world, local_rank):
     plan.want_error(False)  # the analytic error is outside the reference's window (:434-445)
     dist.barrier()
     torch.cuda.synchronize()
-    mg.profile_begin(min_N=N)
+    mg.profile_begin(min_N=0)   # every launch and every ghost exchange of rank 0 (hipEvent pairs)
     t0 = time.perf_counter()
     for _ in range(args.steps):   # back to back on the engine's stream, no per-step host sync
         plan.enqueue()
@@ -116,6 +116,12 @@ def run(args, rank, world, local_rank):
 
     if rank == 0:
         kernels = []
+        exchanges = [{"level_N": e["N"], "what": e["name"], "per_step": e["launches"] // max(1, args.steps),
+                      "avg_ms": round(e["total_ms"] / max(1, e["launches"]), 4), "bytes_per_neighbour_pair": e["algo_bytes"]}
+                     for e in sorted(prof, key=lambda e: -e["N"]) if e["name"].startswith("ghost_exchange")]
+        launches_ms = sum(e["total_ms"] for e in prof if not e["name"].startswith("ghost_exchange")) / max(1, args.steps)
+        exchange_ms = sum(e["total_ms"] for e in prof if e["name"].startswith("ghost_exchange")) / max(1, args.steps)
+        prof = [e for e in prof if e["N"] == N and not e["name"].startswith("ghost_exchange")]
         for e in sorted(prof, key=lambda e: -e["total_ms"]):
             avg = e["total_ms"] / max(1, e["launches"])
             gbs = e["algo_bytes"] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
@@ -138,6 +144,10 @@ def run(args, rank, world, local_rank):
             "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
             "mg_error": r["mg_error"],
             "roofline": roof, "kernels": kernels[:6],
+            # where rank 0's time went (live hipEvent pairs): its kernel launches, its ghost exchanges (which
+            # include waiting for the neighbours), the rest (gaps)
+            "rank0_ms_per_step": {"kernels": round(launches_ms, 4), "ghost_exchanges": round(exchange_ms, 4)},
+            "ghost_exchanges": exchanges,
             **({"transport": "host-staged over gloo, all ranks on ONE GPU: a plumbing rehearsal, not a measurement"}
                if rehearsal else {}),
             "cycle_roofline": {"algorithmic_bytes": algo_bytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world,

@@ -220,6 +220,11 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
     const int R = p->nranks;
     if (R == 1) return;
     if (items.empty() && !share) return;
+    // live timing like every kernel launch (bench.py --gpus N reports it per level): event pair around the group
+    size_t bytes = 0;
+    for (const GhostItem &it : items)
+        bytes += (size_t)2 * (it.depth > 0 ? it.depth : p->depth[(size_t)it.lv->hier]) * it.lv->N * (it.raw ? it.raw_elem : p->elem);
+    ProfScope ps(share ? "ghost_exchange+collapse_allgather" : "ghost_exchange", items.empty() ? share->N : items[0].lv->N, (double)bytes);
     if (p->real) comm_group_begin();
     for (const GhostItem &it : items) {
         Level &lv = *it.lv;
