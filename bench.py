@@ -12,6 +12,7 @@ quoted on: N = 8192^2 fp64.  Prints ONE JSON line (see the driver's contract).
 """
 import argparse
 import json
+import math
 import os
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before libgomp loads (cpu_baseline leg)
@@ -31,6 +32,23 @@ def level_sizes(N, N_min):
         out.append(N)
         N //= 2
     return out
+
+
+def grid_for(world, base=8192, mixed=False):
+    """Weak scaling: ~base^2 points per GPU.  Among the sizes m * 2^j with m <= 64 (every level above the
+    coarse-tail kernel's N <= 64 is then even, so every node runs in its fused one-launch form) the one nearest
+    to base * sqrt(world): 8192, 11520, 16384, 23040 for 1, 2, 4, 8 GPUs."""
+    target = base * math.sqrt(world)
+    best = None
+    for m in range(33, 65):
+        j = max(0, round(math.log2(target / m)))
+        for jj in (j - 1, j, j + 1):
+            if jj < 1:
+                continue
+            n = m * 2 ** jj
+            if best is None or abs(n - target) < abs(best - target):
+                best = n
+    return int(best)
 
 
 def vcycle_algorithmic_bytes(sizes, nu1, nu2):

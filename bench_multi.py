@@ -22,23 +22,6 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0
 
 
-def grid_for(world, base=8192, mixed=False):
-    """Weak scaling: ~base^2 points per GPU.  Among the sizes m * 2^j with m <= 64 (every level above the
-    coarse-tail kernel's N <= 64 is then even, so every node runs in its fused one-launch form) the one nearest
-    to base * sqrt(world): 8192, 11520, 16384, 23040 for 1, 2, 4, 8 GPUs."""
-    target = base * math.sqrt(world)
-    best = None
-    for m in range(33, 65):
-        j = max(0, round(math.log2(target / m)))
-        for jj in (j - 1, j, j + 1):
-            if jj < 1:
-                continue
-            n = m * 2 ** jj
-            if best is None or abs(n - target) < abs(best - target):
-                best = n
-    return int(best)
-
-
 def host_transport(mg, rank, world):
     """Rehearsal wire (MG_BENCH_TRANSPORT=host): ghost rows staged through the host and carried by
     gloo, so that several ranks can share the one GPU of a test box.  Never the measured path."""
@@ -66,7 +49,7 @@ def run(args, rank, world, local_rank):
     else:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import multigrid_poisson_solver_amd as mg
-    from bench import level_sizes, vcycle_algorithmic_bytes
+    from bench import grid_for, level_sizes, vcycle_algorithmic_bytes
 
     mg.init(local_rank)
     mg.set_smoother("stream")

@@ -234,17 +234,17 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
         const int G = it.depth > 0 ? it.depth : p->depth[(size_t)lv.hier];
         const size_t cnt = (size_t)G * N * elem;  // bytes
         auto arr = [&](size_t i) { return it.raw ? (*it.raw)[i] : (it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F); };
-        auto row_at = [&](const mg_slab_plan *, double *a, const RowWindow &w, int n, int y) {
-            return (void *)((char *)a + (size_t)(y - w.base) * n * elem);
+        auto rows_from = [&](double *a, const RowWindow &w, int y) {  // row y of an array with this item's element size
+            return (void *)((char *)a + (size_t)(y - w.base) * N * elem);
         };
         if (!p->real) {
             for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
                 const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
                 double *A = arr((size_t)r), *B = arr((size_t)r + 1);
                 // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
-                (void)hipMemcpyAsync(row_at(p, B, b, N, b.own_lo - G), row_at(p, A, a, N, a.own_hi - G), cnt,
+                (void)hipMemcpyAsync(rows_from(B, b, b.own_lo - G), rows_from(A, a, a.own_hi - G), cnt,
                                      hipMemcpyDeviceToDevice, c.stream);
-                (void)hipMemcpyAsync(row_at(p, A, a, N, a.own_hi), row_at(p, B, b, N, b.own_lo), cnt, hipMemcpyDeviceToDevice,
+                (void)hipMemcpyAsync(rows_from(A, a, a.own_hi), rows_from(B, b, b.own_lo), cnt, hipMemcpyDeviceToDevice,
                                      c.stream);
             }
             continue;
@@ -253,12 +253,12 @@ void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level
         const RowWindow w = window_of(lv.part, r);
         double *A = arr(0);
         if (r + 1 < R) {
-            comm_send(row_at(p, A, w, N, w.own_hi - G), cnt, r + 1);
-            comm_recv(row_at(p, A, w, N, w.own_hi), cnt, r + 1);
+            comm_send(rows_from(A, w, w.own_hi - G), cnt, r + 1);
+            comm_recv(rows_from(A, w, w.own_hi), cnt, r + 1);
         }
         if (r > 0) {
-            comm_send(row_at(p, A, w, N, w.own_lo), cnt, r - 1);
-            comm_recv(row_at(p, A, w, N, w.own_lo - G), cnt, r - 1);
+            comm_send(rows_from(A, w, w.own_lo), cnt, r - 1);
+            comm_recv(rows_from(A, w, w.own_lo - G), cnt, r - 1);
         }
     }
     if (share) share_rows(p, *share, *share_part, true);

@@ -137,3 +137,16 @@ def test_cycle_file_generators(m, tmp_path):
     shipped = _cycles.text("Wcycle.txt").split()
     assert [float(t) for t in w.read_text().split()] == [float(t) for t in shipped]
     assert m.write_vcycle_file(str(v), 8192, 8) == 11
+
+
+def test_weak_scaling_grid_sizes():
+    """bench.py --gpus N: ~8192^2 points per GPU on grids m * 2^j (m <= 64), so that every level above the
+    coarse-tail kernel (N <= 64) has an even size and every node runs in its fused one-launch form."""
+    import bench
+    assert [bench.grid_for(w) for w in (1, 2, 4, 8)] == [8192, 11520, 16384, 23040]
+    for w in range(1, 9):
+        N = bench.grid_for(w)
+        assert abs(N * N / w - 8192 * 8192) < 0.03 * 8192 * 8192
+        sizes = bench.level_sizes(N, 8)
+        assert all(n % 2 == 0 for n in sizes if n > 64), sizes
+        assert sizes[-1] >= 8 and sizes[-1] ** 2 <= 256   # the one-wave coarse solvers cover it
