@@ -250,6 +250,10 @@ int  mg_comm_size(void);
  * others).  Returns the number of levels. */
 int  mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out);
 int  mg_slab_ghost_rows(void);
+/* host-only: ghost rows of each level that actually travel in an exchange (what the level's launches read beyond
+ * the owned rows; 0 for collapsed levels), for `steps` sweeps per node.  Returns the number of levels, -1 when
+ * the halo cannot hold the hierarchy. */
+int  mg_slab_ghost_depths(int N_max, int N_min, int nranks, int collapse_N, int steps, int *out);
 
 typedef struct mg_slab_plan mg_slab_plan;
 /* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:

@@ -81,6 +81,7 @@ ABI = {
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
+    "mg_slab_ghost_depths": (_i, [_i, _i, _i, _i, _i, C.POINTER(_i)]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
@@ -507,6 +508,15 @@ def slab_partition(N_max, N_min, nranks, collapse_N):
         sizes.append(n)
         n //= 2
     return [(sizes[l], bool(coll[l]), [tuple(int(v) for v in out[l, r]) for r in range(nranks)]) for l in range(nl)]
+
+
+def slab_ghost_depths(N_max, N_min, nranks, collapse_N, steps):
+    """mg_slab_ghost_depths: ghost rows per level that travel in an exchange (0 for collapsed levels)."""
+    out = (_i * 64)()
+    n = load_library().mg_slab_ghost_depths(N_max, N_min, nranks, collapse_N, steps, out)   # host-only: no GPU needed
+    if n < 0:
+        raise MGError("mg_slab_ghost_depths: the halo cannot hold this hierarchy")
+    return [int(out[i]) for i in range(n)]
 
 
 def slab_ghost_rows():

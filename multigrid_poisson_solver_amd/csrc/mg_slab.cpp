@@ -39,9 +39,10 @@
 namespace mg {
 namespace {
 
-// Halo rows per side.  S+2 would do for one fused node (mg_stream_impl.h Halo<>); 12 also covers the
-// rows a rank computes REDUNDANTLY on the way up (see ext below), so that the ascent needs no exchange.
-constexpr int GHOST = 12;
+// Halo rows per side.  S+2 would do for one fused node (mg_stream_impl.h Halo<>); 14 also covers the
+// rows a rank computes REDUNDANTLY on the way up (see ext below), so that the ascent needs no exchange
+// (S = 4 sweeps per node: up to 8 redundant rows + the S+2 rows a launch reads beyond them).
+constexpr int GHOST = 14;
 
 struct Partition {
     std::vector<int> lo, hi;  // rows [lo[r], hi[r]) owned by global rank r
@@ -486,6 +487,59 @@ extern "C" {
 
 int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 
+// host-only: (a) ext[l][r] = the rows a `1` node of level l updates on rank r: its owned rows plus what the
+// next finer level's `1` node will read of this level through the prolongation (rows orow[y], orow[y]+1 for
+// every fine row y that launch loads) -- computed redundantly instead of exchanged; (b) depth[l] = the ghost
+// rows of level l that actually travel: what its launches read beyond the owned rows.
+static bool slab_halo_plan(const std::vector<int> &sizes, const std::vector<Partition> &parts, const std::vector<bool> &collapsed,
+                           int nranks, int steps, std::vector<std::vector<std::pair<int, int>>> *ext_out,
+                           std::vector<int> *depth_out)
+{
+    const size_t nl = sizes.size();
+    const int H = steps + 2;  // input rows a launch loads beyond the rows it updates (Halo<S> + 1 spare)
+    std::vector<std::vector<std::pair<int, int>>> ext(nl);
+    for (size_t l = 0; l < nl && !collapsed[l]; ++l) {
+        ext[l].resize((size_t)nranks);
+        std::vector<int> owner;
+        std::vector<double> wh, wl;
+        if (l > 0) {
+            owner.resize((size_t)sizes[l - 1]);
+            wh.resize(owner.size());
+            wl.resize(owner.size());
+            build_prolongation_table(sizes[l], sizes[l - 1], 0, owner.data(), wh.data(), wl.data());
+        }
+        for (int r = 0; r < nranks; ++r) {
+            int lo = parts[l].lo[(size_t)r], hi = parts[l].hi[(size_t)r];
+            if (l > 0) {
+                const int Nf = sizes[l - 1], Nc = sizes[l];
+                const int first = std::max(0, ext[l - 1][(size_t)r].first - H);
+                const int last = std::min(Nf, ext[l - 1][(size_t)r].second + H) - 1;
+                lo = std::min(lo, std::max(0, owner[(size_t)first]));
+                hi = std::max(hi, std::min(Nc, owner[(size_t)last] + 2));
+            }
+            const int own_lo = parts[l].lo[(size_t)r], own_hi = parts[l].hi[(size_t)r];
+            if (own_lo - lo + H > GHOST || hi - own_hi + H > GHOST) {
+                fail(MG_ERR_UNSUPPORTED, "row-slab mode: level %d needs %d redundant rows, more than the halo holds", sizes[l],
+                     std::max(own_lo - lo, hi - own_hi));
+                return false;
+            }
+            ext[l][(size_t)r] = std::make_pair(lo, hi);
+        }
+    }
+    std::vector<int> depth(nl, GHOST);
+    for (size_t l = 0; l < nl && !collapsed[l]; ++l) {
+        int e = 0;
+        for (int r = 0; r < nranks; ++r) {
+            e = std::max(e, parts[l].lo[(size_t)r] - ext[l][(size_t)r].first);
+            e = std::max(e, ext[l][(size_t)r].second - parts[l].hi[(size_t)r]);
+        }
+        depth[l] = std::min(GHOST, e + H);
+    }
+    if (ext_out) *ext_out = ext;
+    if (depth_out) *depth_out = depth;
+    return true;
+}
+
 // host-only: the row ranges each rank owns on every level of the hierarchy a cycle file
 // generates (N_max, halving down to N_min), and which levels are collapsed (replicated on every rank).
 // out[(level*nranks + rank)*2 + {0,1}] = {lo, hi}; collapsed levels report {0, N} for rank 0
@@ -515,6 +569,30 @@ int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out
 }
 
 int mg_slab_ghost_rows(void) { return GHOST; }
+
+// host-only: how many ghost rows of each level actually travel (distributed levels; 0 for collapsed ones) for
+// `steps` sweeps per node; returns the number of levels or -1 when the halo cannot hold the hierarchy
+int mg_slab_ghost_depths(int N_max, int N_min, int nranks, int collapse_N, int steps, int *out)
+{
+    std::vector<int> sizes;
+    for (int n = N_max; n >= N_min && n > 0; n /= 2) sizes.push_back(n);
+    const size_t nl = sizes.size();
+    std::vector<int> ranges(nl * (size_t)nranks * 2), coll(nl);
+    mg_slab_partition(N_max, N_min, nranks, collapse_N, ranges.data(), coll.data());
+    std::vector<Partition> parts(nl);
+    std::vector<bool> collapsed(nl);
+    for (size_t l = 0; l < nl; ++l) {
+        collapsed[l] = coll[l] != 0;
+        for (int r = 0; r < nranks; ++r) {
+            parts[l].lo.push_back(ranges[(l * (size_t)nranks + r) * 2]);
+            parts[l].hi.push_back(ranges[(l * (size_t)nranks + r) * 2 + 1]);
+        }
+    }
+    std::vector<int> depth;
+    if (!slab_halo_plan(sizes, parts, collapsed, nranks, steps, nullptr, &depth)) return -1;
+    for (size_t l = 0; l < nl; ++l) out[l] = collapsed[l] ? 0 : depth[l];
+    return (int)nl;
+}
 
 // rank >= 0: this process is that rank (RCCL communicator from mg_comm_init must exist when
 // nranks > 1).  rank == -1: all nranks slabs live in this process (virtual ranks).
@@ -586,50 +664,9 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
         delete p;
         return nullptr;
     }
-    // rows each `1` node updates: owned rows plus what the next finer level's `1` node will read of this
-    // level through the prolongation (rows orow[y], orow[y]+1 for every fine row y the launch loads)
-    {
-        const int H = p->con_step + 2;  // input rows a launch loads beyond the rows it updates (Halo<S> + 1 spare)
-        p->ext.resize(nl);
-        for (size_t l = 0; l < nl && !p->level_collapsed[l]; ++l) {
-            p->ext[l].resize((size_t)nranks);
-            std::vector<int> owner;
-            std::vector<double> wh, wl;
-            if (l > 0) {
-                owner.resize((size_t)p->sizes[l - 1]);
-                wh.resize(owner.size());
-                wl.resize(owner.size());
-                build_prolongation_table(p->sizes[l], p->sizes[l - 1], 0, owner.data(), wh.data(), wl.data());
-            }
-            for (int r = 0; r < nranks; ++r) {
-                int lo = p->parts[l].lo[(size_t)r], hi = p->parts[l].hi[(size_t)r];
-                if (l > 0) {
-                    const int Nf = p->sizes[l - 1], Nc = p->sizes[l];
-                    const int first = std::max(0, p->ext[l - 1][(size_t)r].first - H);
-                    const int last = std::min(Nf, p->ext[l - 1][(size_t)r].second + H) - 1;
-                    lo = std::min(lo, std::max(0, owner[(size_t)first]));
-                    hi = std::max(hi, std::min(Nc, owner[(size_t)last] + 2));
-                }
-                const int own_lo = p->parts[l].lo[(size_t)r], own_hi = p->parts[l].hi[(size_t)r];
-                if (own_lo - lo + H > GHOST || hi - own_hi + H > GHOST) {
-                    fail(MG_ERR_UNSUPPORTED, "row-slab mode: level %d needs %d redundant rows, more than the halo holds", p->sizes[l],
-                         std::max(own_lo - lo, hi - own_hi));
-                    delete p;
-                    return nullptr;
-                }
-                p->ext[l][(size_t)r] = std::make_pair(lo, hi);
-            }
-        }
-        // ghost rows that travel per level: what its `1` node reads beyond the owned rows (its `-1` node reads H)
-        p->depth.assign(nl, GHOST);
-        for (size_t l = 0; l < nl && !p->level_collapsed[l]; ++l) {
-            int e = 0;
-            for (int r = 0; r < nranks; ++r) {
-                e = std::max(e, p->parts[l].lo[(size_t)r] - p->ext[l][(size_t)r].first);
-                e = std::max(e, p->ext[l][(size_t)r].second - p->parts[l].hi[(size_t)r]);
-            }
-            p->depth[l] = std::min(GHOST, e + H);
-        }
+    if (!slab_halo_plan(p->sizes, p->parts, p->level_collapsed, nranks, p->con_step, &p->ext, &p->depth)) {
+        delete p;
+        return nullptr;
     }
     p->poison = getenv("MG_SLAB_POISON") != nullptr;
     size_t smoothing_nodes = 0;

@@ -56,7 +56,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     orc = _oracle.Oracle()
-    G = mg.slab_ghost_rows()
+    G = mg.slab_ghost_rows()                                  # halo rows a slab carries
+    depth = mg.slab_ghost_depths(N, 8, world, collapse, step)  # ... and how many of them travel, per level
     levels = mg.slab_partition(N, 8, world, collapse)
     sizes = [l[0] for l in levels]
     L = 1.0
@@ -91,12 +92,12 @@ def main():
         # level's F halo: it is needed when the cycle comes back up through this level
         Ul = np.full((n, n), np.nan)
         Ul[lo:hi] = U[l][lo:hi]
-        exchange(Ul, lo, hi, G, rank, world)
+        exchange(Ul, lo, hi, depth[l], rank, world)
         U[l] = Ul
         if l + 1 < first_collapsed:
             F[l + 1] = np.full((M, M), np.nan)
             F[l + 1][clo:chi] = Fc[clo:chi]
-            exchange(F[l + 1], clo, chi, G, rank, world)
+            exchange(F[l + 1], clo, chi, depth[l + 1], rank, world)
         else:
             parts = [None] * world
             dist.all_gather_object(parts, (clo, chi, Fc[clo:chi].copy()))

@@ -167,3 +167,19 @@ def test_fresh_slab_arrays_are_poisoned(mg, tmp_path):
     assert plan.execute()["status"] == 0
     assert not np.isnan(plan.gather_U(512)).any()
     plan.close()
+
+
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_virtual_slabs_deep_hierarchy_other_sweep_counts(mg, oracle, tmp_path, steps):
+    """8 slabs, five distributed levels, 1 / 2 / 4 sweeps per node: the redundant halo rows of the ascent
+    (up to 8 per side at 4 sweeps) plus the rows a launch reads beyond them have to fit the halo."""
+    N = 2048
+    path = str(tmp_path / "V.txt")
+    mg.write_vcycle_file(path, N, 8, steps, 1e-7)
+    depths = mg.slab_ghost_depths(N, 8, 8, 64, steps)
+    assert max(depths) <= mg.slab_ghost_rows() and depths[0] == steps + 2
+    want = oracle.run_cycle_file(path)
+    plan = mg.SlabPlan(path, 8, -1, 64)
+    got = plan.execute()
+    check(got, plan.gather_U(N), want)
+    plan.close()
