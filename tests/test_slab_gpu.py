@@ -22,7 +22,7 @@ def check(got, U, want):
         assert g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
 
 
-@pytest.mark.parametrize("R", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("R", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("collapse", [64, 256])
 def test_virtual_slabs_vcycle_vs_oracle(mg, oracle, tmp_path, R, collapse):
     N = 1024
