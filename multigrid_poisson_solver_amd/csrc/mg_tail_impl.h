@@ -228,16 +228,27 @@ __device__ void gauss_seidel_wave_lds(int N, double h2, double inv, int u, bool 
         const double denom = (double)((N - 2) * (N - 2));
         // `sum/denom > tol` without the division wherever rounding cannot matter (see gsw::solve)
         const double thr = tol * denom, thr_hi = thr * (1.0 + 0x1p-48), thr_lo = thr * (1.0 - 0x1p-48);
+        // own value and the four neighbours of every point stay in registers between the passes: the read
+        // that closes an iteration (all neighbours of the final iterate, for the norm) is also the read the
+        // next red pass needs, so an iteration is two LDS round trips (black pass, closing read), not three
+        double own[GS_WAVE_PTS], nw[GS_WAVE_PTS], ne[GS_WAVE_PTS], nn[GS_WAVE_PTS], ns[GS_WAVE_PTS];
+#pragma unroll
+        for (int k = 0; k < GS_WAVE_PTS; ++k) own[k] = nw[k] = ne[k] = nn[k] = ns[k] = 0.0;
         int iterations = 0;
         for (;;) {
 #pragma unroll
-            for (int colour = 0; colour < 2; ++colour) {
+            for (int k = 0; k < GS_WAVE_PTS; ++k) {  // red :1020 -- neighbours from the closing read
+                if (inner[k] && red[k]) {
+                    own[k] = 0.25 * (nw[k] + ne[k] + nn[k] + ns[k] - h2f[k]);
+                    GSD(u, q[k]) = own[k];
+                }
+            }
 #pragma unroll
-                for (int k = 0; k < GS_WAVE_PTS; ++k) {
-                    if (inner[k] && red[k] == (colour == 0)) {  // :1020, :1043
-                        const int p = q[k];
-                        GSD(u, p) = 0.25 * (GSD(u, p - 1) + GSD(u, p + 1) + GSD(u, p + N) + GSD(u, p - N) - h2f[k]);
-                    }
+            for (int k = 0; k < GS_WAVE_PTS; ++k) {  // black :1043
+                if (inner[k] && !red[k]) {
+                    const int p = q[k];
+                    own[k] = 0.25 * (GSD(u, p - 1) + GSD(u, p + 1) + GSD(u, p + N) + GSD(u, p - N) - h2f[k]);
+                    GSD(u, p) = own[k];
                 }
             }
             ++iterations;
@@ -246,7 +257,11 @@ __device__ void gauss_seidel_wave_lds(int N, double h2, double inv, int u, bool 
             for (int k = 0; k < GS_WAVE_PTS; ++k) {
                 if (inner[k]) {
                     const int p = q[k];
-                    const double rs = inv * (GSD(u, p + N) + GSD(u, p - N) + GSD(u, p + 1) + GSD(u, p - 1) - 4 * GSD(u, p)) - f[k];  // :560
+                    nw[k] = GSD(u, p - 1);
+                    ne[k] = GSD(u, p + 1);
+                    nn[k] = GSD(u, p + N);
+                    ns[k] = GSD(u, p - N);
+                    const double rs = inv * (nn[k] + ns[k] + ne[k] + nw[k] - 4 * own[k]) - f[k];  // :560
                     acc += fabs(rs);
                 }
             }
