@@ -142,6 +142,11 @@ __device__ __forceinline__ float from_lane_above(float v)
 
 // x / c for a constant c: div_by_const(x, c, RN(1/c)), see mg_divconst.h
 
+// a - 4*u with one rounding: the product 4*u is exact in binary floating point, so the fused form is bit-identical
+// to the reference's `... - 4*U` (src/MG_solver_CPU.cpp:590, :560) under -ffp-contract=off
+__device__ __forceinline__ double minus4(double a, double u) { return __builtin_fma(-4.0, u, a); }
+__device__ __forceinline__ float minus4(float a, float u) { return __builtin_fmaf(-4.0f, u, a); }
+
 // Read-only host-built tables are read through the constant address space: the compiler may
 // then use scalar loads (s_load, SGPR result, lgkmcnt) for wave-uniform indices instead of
 // vector loads that would queue behind the streaming loads in vmcnt order.
@@ -486,7 +491,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const real_t w = j == 0 ? west0 : c.v[j > 0 ? j - 1 : 0];
                     const real_t e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
                     // src/MG_solver_CPU.cpp:590: U += 0.25*(U[i+1]+U[i-1]+U[j+1]+U[j-1] - 4U - dx^2 F)
-                    const real_t t = nw.v[j] + so.v[j] + e + w - 4 * c.v[j] - dx2 * fq[l].v[j];
+                    // `- 4*U` through one fma: 4*U is exact, so fma(-4, U, a) is the same bits as a - 4*U (one VALU op less)
+                    const real_t t = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - dx2 * fq[l].v[j];
                     o.v[j] = c.v[j] + real_t(0.25) * t;
                 }
                 if (row_edge) {  // wave-uniform, two rows of the whole grid: the rim keeps its value
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 for (int j = 0; j < COLS; ++j) {
                     const real_t w = j == 0 ? west0 : c.v[j > 0 ? j - 1 : 0];
                     const real_t e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
-                    const real_t r = inv * (nw.v[j] + so.v[j] + e + w - 4 * c.v[j]) - fq[S + 1].v[j];
+                    const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - fq[S + 1].v[j];
                     const bool interior = !(row_edge || col_edge[j]);
                     const real_t dv = interior ? r : real_t(0.0);
                     d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
