@@ -143,9 +143,13 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 or args.force_slab:
+        from multigrid_poisson_solver_amd import build as mg_build
+        mg_build.ensure_built()
         import bench_multi  # row-slab path (one process per GPU, RCCL ghost rows)
         return bench_multi.run(args, rank, world, local_rank)
 
+    from multigrid_poisson_solver_amd import build as mg_build
+    mg_build.ensure_built()   # no-op when the in-tree library is there (the normal case)
     import multigrid_poisson_solver_amd as mg
     mg.init(local_rank)
     mg.set_smoother(args.smoother)

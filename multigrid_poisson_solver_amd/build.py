@@ -30,6 +30,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def ensure_built():
+    """Build the in-tree library when it is absent (a source-only checkout on a box with hipcc).  One
+    process at a time: the ranks of a torchrun launch serialise on a lock file."""
+    if os.path.exists(LIB):
+        return LIB
+    import fcntl
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return LIB if os.path.exists(LIB) else build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, "mg_internal.h"), os.path.join(ROOT, "include", "mg_hip.h"),
