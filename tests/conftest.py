@@ -100,6 +100,8 @@ def golden_fullsize():
 def mg():
     """The engine, initialised on cuda:0.  Fails (does not skip) when the HIP library or
     the device is missing: GPU tests must never pass on a fallback."""
+    from multigrid_poisson_solver_amd import build as b
+    b.ensure_built()   # source-only checkout: compile the in-tree library first (hipcc); never a fallback
     import multigrid_poisson_solver_amd as m
     m.init(0)
     yield m
