@@ -150,3 +150,25 @@ def test_weak_scaling_grid_sizes():
         sizes = bench.level_sizes(N, 8)
         assert all(n % 2 == 0 for n in sizes if n > 64), sizes
         assert sizes[-1] >= 8 and sizes[-1] ** 2 <= 256   # the one-wave coarse solvers cover it
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_bench_line.json is what bench.py printed on the MI355X: the keys the driver and the judge
+    read must be there, the roofline must be priced consistently, the traffic file must cover the dominant kernel."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "MLUPS" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "8192" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is not None and 0.9 < r["traffic"] / r["hbm"]["compulsory_bytes"] < 1.2   # counters vs compulsory bytes
+    assert 0.4 < r["hbm"]["frac"] < 1.0
+    lups = 6 * sum((8192 >> l) ** 2 for l in range(10))
+    assert abs(d["value"] - lups / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c and c["value"] > 0
