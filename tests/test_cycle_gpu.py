@@ -244,3 +244,18 @@ def test_cycles_whose_coarsest_level_has_65_to_256_points(mg, oracle, tmp_path, 
     check_against(got, want, zero_sign=True)
     assert mg.lastExactSolverIterations() == oracle.gs_iterations()
     plan.close()
+
+
+def test_w_cycle_revisits_are_idempotent_in_the_reference_semantics(mg, oracle, tmp_path):
+    """Observation recorded in DESIGN.md section 8: the reference zeroes U on every descent (:252-257), so the
+    repeated visits of its W-cycle recompute identical values and the W-cycle ends on the V-cycle's U, bit for
+    bit -- in the oracle and in the engine alike (the engine executes every visit, as the reference does)."""
+    v, w = str(tmp_path / "V.txt"), str(tmp_path / "W.txt")
+    mg.write_vcycle_file(v, 256, 8, 3, 1e-7)
+    mg.write_wcycle_file(w, 256, 8, 3, 1e-7)
+    ov, ow = oracle.run_cycle_file(v), oracle.run_cycle_file(w)
+    assert np.array_equal(ov["U"], ow["U"]) and len(ow["records"]) > len(ov["records"])
+    gv = mg.CyclePlan(v, fused=True).execute(fetch_U=True)
+    gw = mg.CyclePlan(w, fused=True).execute(fetch_U=True)
+    assert np.array_equal(gv["U"], gw["U"])
+    assert len(gw["records"]) == len(ow["records"])
