@@ -268,10 +268,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         lane_owns = lane_owns && x >= own_x0 && x < own_x0 + OW && x < N;
     }
     const bool lane_loads = col_in[0] && col_in[COLS - 1];  // COLS == 2: N even, xl even
-    // does ANY lane of this wave hold a rim column (x <= 0 or x >= N-1)?  wave-uniform: only the
-    // first and last strips do, every other wave skips the per-point rim selects
-    const bool wave_has_rim_col = (own_x0 - H) <= 0 || (own_x0 - H + W - 1) >= N - 1;
-
     const real_t dx2 = p.dx2, inv = p.inv;
     const bool nt_stores = N >= p.nt_min_n;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
@@ -495,12 +491,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const real_t t = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - dx2 * fq[l].v[j];
                     o.v[j] = c.v[j] + real_t(0.25) * t;
                 }
-                if (row_edge) {  // wave-uniform, two rows of the whole grid: the rim keeps its value
-                    o = c;
-                } else if (wave_has_rim_col) {  // wave-uniform, two strips of the whole grid
+                // the rim keeps its value: ONE select per value on the merged condition (the compiler turns the
+                // two nested wave-uniform cases into two selects per value otherwise: 12 more VALU ops per row)
 #pragma unroll
-                    for (int j = 0; j < COLS; ++j) o.v[j] = col_edge[j] ? c.v[j] : o.v[j];
-                }
+                for (int j = 0; j < COLS; ++j) o.v[j] = (row_edge || col_edge[j]) ? c.v[j] : o.v[j];
                 older[l - 1] = c;
                 newer[l - 1] = nw;
                 nw = o;
