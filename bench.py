@@ -9,13 +9,22 @@ V(3,3) cycle-structure file -- level push/pop, smoothing, residual, restriction,
 Gauss-Seidel solve, prolongation, correction -- from the state right after getSource,
 inputs resident in HBM.  At --gpus 1 the workload is the configuration the metric is
 quoted on: N = 8192^2 fp64.  Prints ONE JSON line (see the driver's contract).
+
+--gpus N > 1 without a torchrun environment: this process starts the N ranks itself (a child
+`python -m torch.distributed.run`, before anything here touches the GPU) and relays rank 0's line.
+Every line carries two legs: `value` = weak scaling (8192^2 points per GPU, the headline) and
+`strong_scaling` = the V-cycle at N = 16384^2 on the same GPUs (BASELINE.json configs[3]; the
+>= 6x target of north_star is quoted there), at N = 1 as the one-GPU base of that curve.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before libgomp loads (cpu_baseline leg)
+import statistics
+import subprocess
 import sys
 import tempfile
 import time
@@ -24,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STRONG_N = 16384       # BASELINE.json configs[3]: V-cycle N=16384^2, row slabs
 
 
 def level_sizes(N, N_min):
@@ -52,20 +62,41 @@ def grid_for(world, base=8192, mixed=False):
 
 
 def vcycle_algorithmic_bytes(sizes, nu1, nu2):
-    """B = sum_{l<Lc} [(8 + 24 nu1 + 24 + 8 + 16 + 24 nu2) n_l + 16 n_{l+1}]."""
+    """B = sum_{l<Lc} [(8 + 24 nu1 + 24 + 8 + 16 + 24 nu2) n_l + 16 n_{l+1}]
+    (operator by operator: every sweep a pass of its own)."""
     total = 0.0
     for a, b in zip(sizes[:-1], sizes[1:]):
         total += (8 + 24 * nu1 + 24 + 8 + 16 + 24 * nu2) * a * a + 16.0 * b * b
     return total
 
 
+def vcycle_compulsory_bytes(sizes):
+    """HBM bytes one V-cycle of the FUSED driver cannot avoid: per level one `-1` launch (F in, U out, coarse F
+    out: 16 n + 8 m) and one `1` launch (U, F, coarse U in, U out: 24 n + 8 m).  The coarse tail (N <= 64) lives
+    in LDS and is not counted."""
+    total = 0.0
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        if a <= 64:
+            break
+        total += 40.0 * a * a + 16.0 * b * b
+    return total
+
+
+def lib_sha():
+    import multigrid_poisson_solver_amd as mg
+    h = hashlib.sha256()
+    with open(mg.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel_family):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json, produced by scripts/profile.sh on the same command)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    data = json.load(open(path)).get("kernels", {})
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC run (profiles/rNN_traffic.json,
+    scripts/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes over this very command, FETCH x2 on gfx950).  The
+    counters cannot be collected inside a timed bench run, so the record is tied to the library it was measured
+    on: it is reported only when the sha of the loaded libmgpoisson.so equals the profiled one, else null."""
+    import glob
     import re
     m = re.match(r"jacobi_stream<(\d)(.*)>", kernel_family)
     if not m:
@@ -73,11 +104,18 @@ def measured_traffic(kernel_family):
     steps, rest = m.group(1), m.group(2)
     mode = "2" if "prolong" in rest else ("1" if "zero" in rest else "0")
     restrict = "true" if "restrict" in rest else "false"
-    # the finest-level launch is the variant that moved the most bytes (the same template with
-    # another prefetch depth serves the small levels)
-    hits = [v["total_bytes"] for name, v in data.items()
-            if name.split("::")[-1].startswith(f"k_jacobi_stream<{steps}, 2, {mode}, {restrict}") and not name.startswith("f32::")]
-    return max(hits) if hits else None
+    sha = lib_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        rec = json.load(open(path))
+        if rec.get("lib_sha") != sha:
+            continue
+        # the finest-level launch is the variant that moved the most bytes (the same template serves the small levels)
+        hits = [v["total_bytes"] for name, v in rec.get("kernels", {}).items()
+                if name.split("::")[-1].startswith(f"k_jacobi_stream<{steps}, 2, {mode}, {restrict}") and not name.startswith("f32::")]
+        if hits:
+            return {"bytes": max(hits), "source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                    "lib_sha": sha}
+    return None
 
 
 def compulsory_bytes(kernel_family, N):
@@ -95,26 +133,104 @@ def compulsory_bytes(kernel_family, N):
     return None
 
 
-def cpu_baseline(cycle_path, lups, threads=None):
-    """The reference's own operators (oracle/_ref/libmgref.so, built from /root/reference by
-    oracle/Makefile) -- or, when that build is absent, the oracle's restatement -- timed on
-    this host's cores over ONE run of the same cycle file, in the reference's own window.
+def cpu_baseline(tmp, N, n_min, nu, write_vcycle_file):
+    """The reference's own operators (oracle/_ref/libmgref*.so, built from /root/reference by oracle/Makefile)
+    -- or, when that build is absent, the oracle's restatement -- timed on this host's cores in the reference's
+    own window (src/MG_solver_CPU.cpp:156..429).  BASELINE.md section 3: both builds (-O2 and the shipped
+    Makefile's flags, src/Makefile:8: no -O), all of the job's cores and one thread, >= 3 repetitions with
+    min/median for the headline variant; bounded to ~20 s of CPU work.
     TEST/BASELINE infrastructure: reported beside the GPU number, never part of it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
     orc = _oracle.Oracle()
-    # a 1-GPU job owns 16 host cores on the GPU box, whatever os.cpu_count() says
-    cores = threads or min(16, os.cpu_count() or 1)
-    orc.set_threads(cores)
-    ops, kind = None, "port"
-    if _oracle.have_reference():
-        ops, kind = _oracle.Reference(), "reference"
-        ops.set_threads(cores)
-    res = orc.run_cycle_file(cycle_path, ops=ops, want_report=False)
-    if res["status"] != 0:
+    cores = min(16, os.cpu_count() or 1)  # a 1-GPU job owns 16 host cores on the GPU box, whatever os.cpu_count() says
+    have_ref = _oracle.have_reference()
+    kind = "reference" if have_ref else "port"
+
+    def timed(n, threads, reps, makefile_flags=False):
+        path = os.path.join(tmp, f"cpu_Vcycle_{n}.txt")
+        write_vcycle_file(path, n, n_min, nu, 1e-7)
+        lups = sum(2 * nu * s * s for s in level_sizes(n, n_min)[:-1])
+        ops = None
+        if have_ref:
+            ops = _oracle.Reference(makefile_flags=makefile_flags)
+            ops.set_threads(threads)
+        orc.set_threads(threads)
+        ts, err = [], None
+        for _ in range(reps):
+            res = orc.run_cycle_file(path, ops=ops, want_report=False)
+            if res["status"] != 0:
+                return None
+            ts.append(res["time_ms"])
+            err = res["mg_error"]
+        return {"N": n, "threads": threads, "reps": reps, "min_ms": round(min(ts), 2), "median_ms": round(statistics.median(ts), 2),
+                "value": round(lups / (min(ts) * 1e-3) / 1e6, 3), "unit": "MLUPS", "mg_error": err}
+
+    head = timed(N, cores, 3)
+    if not head:
         return None
-    return {"value": round(lups / (res["time_ms"] * 1e-3) / 1e6, 3), "unit": "MLUPS", "cores": cores, "kind": kind,
-            "time_ms": round(res["time_ms"], 2), "mg_error": res["mg_error"]}
+    out = {"value": head["value"], "unit": "MLUPS", "cores": cores, "kind": kind, "time_ms": head["min_ms"],
+           "median_ms": head["median_ms"], "reps": 3, "mg_error": head["mg_error"],
+           "sample": (f"V({nu},{nu})-cycle at N={N}^2, the reference's timed window, 3 runs (value = fastest), "
+                      f"{'reference operators (oracle/_ref/libmgref.so, g++ -O2 -fopenmp)' if have_ref else 'oracle restatement (-O2)'}"
+                      f", {cores} OpenMP threads"),
+           "variants": {}}
+    small = min(N, 4096)
+    if have_ref and os.path.exists(_oracle.REF_SO_MAKEFLAGS):
+        v = timed(N, cores, 1, makefile_flags=True)
+        if v:
+            v["build"] = "g++ -fopenmp (src/Makefile:8: no -O)"
+            out["variants"]["makefile_flags"] = v
+    v = timed(small, 1, 1)
+    if v:
+        v["build"] = "g++ -O2 -fopenmp" if have_ref else "oracle -O2"
+        out["variants"]["one_thread"] = v
+    return out
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD process (never exec: this interpreter may be
+    preloaded by a profiler) before anything in this process has touched the GPU, relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MG_BENCH_N"] = str(args.n)  # torchrun's own parser would eat a bare --n
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return child.returncode if child.returncode != 0 else (0 if line else 1)
+
+
+def time_cycle(mg, plan, steps, warmup, profile_min_N=None):
+    """W untimed runs, then exactly K windows enqueued back to back on the engine's stream (a fixed-step cycle
+    file needs no per-step host sync), bracketed by synchronisation; optional live hipEvent pairs."""
+    first = None
+    for _ in range(warmup):
+        first = plan.execute()
+        assert first["status"] == 0, first
+    mg.sync()
+    if profile_min_N is not None:
+        mg.profile_begin(min_N=profile_min_N)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.enqueue()
+    mg.sync()
+    t1 = time.perf_counter()
+    r = plan.collect()
+    prof = mg.profile_end() if profile_min_N is not None else []
+    assert r["status"] == 0, r
+    return (t1 - t0) * 1e3 / steps, r, prof
 
 
 def main():
@@ -129,27 +245,30 @@ def main():
     ap.add_argument("--cycle", choices=["V", "W"], default="V")
     ap.add_argument("--mode", choices=["eager", "graph", "unfused"], default="eager")
     ap.add_argument("--smoother", choices=["stream", "simple"], default=os.environ.get("MG_SMOOTHER", "stream"))
-    ap.add_argument("--cpu-n", type=int, default=None, help="grid size of the CPU baseline sample (default: --n)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the N=16384 strong-scaling leg")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("MG_BENCH_SCALING", "weak"),
+                    help="which leg is the line's `value` (the other one is nested)")
     ap.add_argument("--mixed", action="store_true",
                     help="mixed-precision mode (fp32 cycle, fp64 source/result; NOT the headline metric, which is fp64)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the row-slab/RCCL leg even with one rank (plumbing rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))  # nothing above has touched the GPU
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 or args.force_slab:
-        from multigrid_poisson_solver_amd import build as mg_build
-        mg_build.ensure_built()
+    from multigrid_poisson_solver_amd import build as mg_build
+    mg_build.ensure_built()   # no-op when the in-tree library is there (the normal case)
+    if world > 1 or args.force_slab:
         import bench_multi  # row-slab path (one process per GPU, RCCL ghost rows)
         return bench_multi.run(args, rank, world, local_rank)
 
-    from multigrid_poisson_solver_amd import build as mg_build
-    mg_build.ensure_built()   # no-op when the in-tree library is there (the normal case)
     import multigrid_poisson_solver_amd as mg
     mg.init(local_rank)
     mg.set_smoother(args.smoother)
@@ -171,79 +290,84 @@ def main():
 
     plan = mg.CyclePlan(cyc, fused=(args.mode != "unfused"), graph=(args.mode == "graph"), report=False, error=False,
                         mixed=args.mixed)
-    first = None
-    for _ in range(max(args.warmup, 2 if args.mode == "graph" else 0)):
-        first = plan.execute()
-        assert first["status"] == 0, first
-
     # ---- timed region: exactly K steps, bracketed by synchronisation on both sides ----
-    mg.sync()
-    mg.profile_begin(min_N=N)          # hipEvent pairs around the finest-level launches
-    t0 = time.perf_counter()
-    dev_ms = 0.0
-    # the K windows are enqueued back to back on the engine's stream (no per-step host sync: a
-    # fixed-step cycle file needs none) and the region ends with one synchronisation
-    for _ in range(args.steps):
-        plan.enqueue()
-    mg.sync()
-    t1 = time.perf_counter()
-    r = plan.collect()
-    dev_ms = r["device_ms"] * args.steps
-    prof = mg.profile_end()
-    assert r["status"] == 0
-    ms_per_step = (t1 - t0) * 1e3 / args.steps
+    ms_per_step, r, prof = time_cycle(mg, plan, args.steps, max(args.warmup, 2 if args.mode == "graph" else 0), profile_min_N=N)
+    dev_ms = r["device_ms"]
     mlups = lups / (ms_per_step * 1e-3) / 1e6
+    elem = 0.5 if args.mixed else 1.0
 
     # dominant kernel = the launch family with the largest total time on the finest grid
     roof = None
     kernels = []
     for e in sorted(prof, key=lambda e: -e["total_ms"]):
         avg = e["total_ms"] / max(1, e["launches"])
-        gbs = e["algo_bytes"] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        cb = compulsory_bytes(e["name"], N)
         kernels.append({"kernel": e["name"], "N": e["N"], "launches": e["launches"], "avg_ms": round(avg, 4),
-                        "algo_GBs": round(gbs, 1)})
-    if kernels:
+                        "compulsory_GBs": round(cb * elem / (avg * 1e-3) / 1e9, 1) if cb and avg > 0 else None,
+                        "algorithmic_equiv_GBs": round(e["algo_bytes"] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None})
+    if kernels and kernels[0]["compulsory_GBs"]:
         k0 = kernels[0]
-        roof = {"bound": "hbm", "kernel": k0["kernel"], "achieved": k0["algo_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(k0["algo_GBs"] / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(k0["kernel"]) if N == 8192 and not args.mixed else None,
-                "avg_ms": k0["avg_ms"], "launches": k0["launches"]}
-        # `achieved` prices the launch at SURVEY section 8d's 24 B per lattice update, which the
-        # temporally blocked kernel undercuts (S sweeps per pass over HBM): frac > 1 is that
-        # saving, not a bandwidth.  What the launch really has to move, and how fast it moves it:
-        cb = compulsory_bytes(k0["kernel"], N)
-        if cb and args.mixed:
-            cb /= 2
-        if cb:
-            g = cb / (k0["avg_ms"] * 1e-3) / 1e9
-            roof["hbm"] = {"compulsory_bytes": cb, "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(g / HBM_PEAK_GBS, 4)}
+        cb = compulsory_bytes(k0["kernel"], N) * elem
+        # `achieved`/`frac`: the bytes the launch must move (every input read once, every output written once)
+        # over its measured duration -- a physical bandwidth.  SURVEY section 8d's per-sweep accounting
+        # (24 B per lattice update and sweep) is kept under `algorithmic_equiv`: the temporally blocked kernel
+        # does S sweeps per pass over HBM, so that figure exceeds the peak and is a saving, not a bandwidth.
+        roof = {"bound": "hbm", "kernel": k0["kernel"], "achieved": k0["compulsory_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(k0["compulsory_GBs"] / HBM_PEAK_GBS, 4), "compulsory_bytes": cb,
+                "traffic": measured_traffic(k0["kernel"]) if not args.mixed else None,
+                "avg_ms": k0["avg_ms"], "launches": k0["launches"],
+                "algorithmic_equiv": {"bytes": next(e["algo_bytes"] for e in prof if e["name"] == k0["kernel"]),
+                                      "GBs": k0["algorithmic_equiv_GBs"],
+                                      "note": "SURVEY 8d bytes (one HBM pass per sweep) / launch time; > peak because S sweeps share one pass"}}
 
     out = {
         "metric": "vcycle_mlups", "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
         "config": {"workload": f"{args.cycle}({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'}, {len(sizes)} levels to N={sizes[-1]}, "
-                               f"red-black GS(1e-7) coarse solve, cycle-file driver ({args.mode}, {args.smoother} smoother)",
+                               f"red-black GS(1e-7) coarse solve, cycle-file driver ({args.mode}, {args.smoother} smoother: "
+                               f"temporally blocked wave-streaming kernels, halos in registers via DPP lane shifts, no LDS tiles)",
                    "N": N, "levels": len(sizes), "cycle_file": os.path.basename(cyc)},
-        "device_ms_per_step": round(dev_ms / args.steps, 4),
+        "device_ms_per_step": round(dev_ms, 4),
         "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
         "mg_error": plan.analytic_error(r),
         "roofline": roof,
         "kernels": kernels[:8],
     }
     if algo_bytes:
-        gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9
-        out["cycle_roofline"] = {"algorithmic_bytes": algo_bytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        cb = vcycle_compulsory_bytes(sizes) * elem
+        out["cycle_roofline"] = {"compulsory_bytes": cb, "achieved": round(cb / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(cb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "algorithmic_equiv": {"bytes": algo_bytes, "GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1)}}
     plan.close()
+    mg.lib().mg_pool_trim()
 
-    # north_star's own yardstick, measured beside the cycle: ONE fine-level Jacobi sweep per
-    # launch (doSmoothing with step = 1, 24 algorithmic bytes per point), both smoothers
+    # ---- strong-scaling base: the V-cycle of BASELINE.json configs[3] (N = 16384^2) on this one GPU ----
+    if not args.no_strong and args.cycle == "V" and N != STRONG_N:
+        try:
+            scyc = os.path.join(tmp, f"Vcycle_{STRONG_N}.txt")
+            mg.write_vcycle_file(scyc, STRONG_N, args.n_min, nu, 1e-7)
+            ssizes = level_sizes(STRONG_N, args.n_min)
+            slups = sum(2 * nu * s * s for s in ssizes[:-1])
+            splan = mg.CyclePlan(scyc, fused=True, report=False, error=False, mixed=args.mixed)
+            sms, sr, _ = time_cycle(mg, splan, args.steps, max(1, args.warmup))
+            scb = vcycle_compulsory_bytes(ssizes) * elem
+            out["strong_scaling"] = {"N": STRONG_N, "n_gpus": 1, "ms_per_step": round(sms, 4), "value": round(slups / (sms * 1e-3) / 1e6, 1),
+                                     "unit": "MLUPS", "steps": args.steps, "scaling": "strong",
+                                     "workload": f"V({nu},{nu})-cycle N={STRONG_N}^2 fp64 (BASELINE.json configs[3]), one GPU: the base of the strong-scaling curve",
+                                     "cycle_frac_of_hbm_peak": round(scb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            splan.close()
+            mg.lib().mg_pool_trim()
+        except mg.MGError as exc:
+            out["strong_scaling"] = {"error": str(exc)}
+
+    # north_star's own yardstick, measured beside the cycle: ONE fine-level Jacobi sweep per launch (doSmoothing with
+    # step = 1, 24 B per point: compulsory == algorithmic here) -- the one-row-per-block pair kernel that the engine
+    # routes a bare sweep of a large grid to, and the streaming kernel at S = 1 (smoother "stream_only")
     try:
         Ua, Ub, Ff = mg.DeviceGrid.uniform(N, 3), mg.DeviceGrid(N), mg.DeviceGrid.uniform(N, 7)
         single = {}
-        for sm in ("stream", "simple"):
+        for sm in ("stream", "stream_only"):
             mg.set_smoother(sm)
             for _ in range(3):
                 mg.smooth_pp(N, 1.0, Ua, Ub, Ff, 1)
@@ -254,8 +378,9 @@ def main():
             e = mg.profile_end()[0]
             avg = e["total_ms"] / e["launches"]
             gbs = 24.0 * N * N / (avg * 1e-3) / 1e9
-            single[sm] = {"kernel": e["name"], "avg_ms": round(avg, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            single["k_" + e["name"].split("<")[0] + ("_S1" if "stream" in e["name"] else "")] = {
+                "launch": e["name"], "avg_ms": round(avg, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         out["single_sweep_roofline"] = single
         mg.set_smoother(args.smoother)
         # the box's own device-to-device copy rate: the practical ceiling SURVEY.md 8d asks for
@@ -272,20 +397,16 @@ def main():
     except mg.MGError as exc:  # never let the side measurement take the bench line down
         out["single_sweep_roofline"] = {"error": str(exc)}
 
+    if args.scaling == "strong" and isinstance(out.get("strong_scaling"), dict) and "value" in out["strong_scaling"]:
+        s = out["strong_scaling"]
+        out["weak_scaling"] = {"N": N, "value": out["value"], "ms_per_step": out["ms_per_step"]}
+        out.update(value=s["value"], ms_per_step=s["ms_per_step"], scaling="strong")
+        out["config"]["workload"] = s["workload"]
+        out["config"]["N"] = STRONG_N
+
     if not args.no_cpu:
-        cpu_n = args.cpu_n or N
-        cpu_cyc = cyc
-        cpu_lups = lups
-        if cpu_n != N or args.cycle != "V":
-            cpu_cyc = os.path.join(tmp, f"cpu_Vcycle_{cpu_n}.txt")
-            mg.write_vcycle_file(cpu_cyc, cpu_n, args.n_min, nu, 1e-7)
-            cs = level_sizes(cpu_n, args.n_min)
-            cpu_lups = sum(2 * nu * s * s for s in cs[:-1])
-        base = cpu_baseline(cpu_cyc, cpu_lups)
+        base = cpu_baseline(tmp, N, args.n_min, nu, mg.write_vcycle_file)
         if base:
-            base["sample"] = (f"1 V({nu},{nu})-cycle at N={cpu_n}^2 (the reference's timed window, "
-                              f"{'reference operators oracle/_ref' if base['kind'] == 'reference' else 'oracle restatement'}"
-                              f", -O2, {base['cores']} OpenMP threads)")
             out["cpu_baseline"] = base
     mg.finalize()
     print(json.dumps(out))

@@ -1,17 +1,19 @@
 """bench_multi.py -- the --gpus N > 1 leg of bench.py: one process per GPU (launched by
-torch.distributed.run), 1-D row slabs, ghost rows over RCCL/xGMI.
+torch.distributed.run, or by bench.py itself), 1-D row slabs, ghost rows over RCCL/xGMI.
 
-Weak scaling: the per-GPU share of the finest grid stays at the 8192^2 points the
-single-GPU metric is quoted on, so the grid is N_g x N_g with N_g ~ 8192*sqrt(gpus)
-(8192, 11520, 16384, 23040 for 1, 2, 4, 8 GPUs: sizes m * 2^j with m <= 64, so that every level
-above the coarse-tail kernel keeps an even size).  `value` is the whole-job aggregate: lattice updates of one
-V(3,3)-cycle over ALL slabs divided by the slowest rank's time.
+Two legs per run, both in the one JSON line rank 0 prints:
+  weak   (`value`): the per-GPU share of the finest grid stays at the 8192^2 points the single-GPU metric is
+         quoted on, so the grid is N_g x N_g with N_g ~ 8192*sqrt(gpus) (8192, 11520, 16384, 23040 for 1, 2, 4, 8
+         GPUs: sizes m * 2^j with m <= 64, so that every level above the coarse-tail kernel keeps an even size);
+  strong (`strong_scaling`): the V-cycle at N = 16384^2 (BASELINE.json configs[3]; north_star's >= 6x at 8 GPUs
+         is quoted on it) cut into `gpus` slabs -- the one-GPU base of that curve is in bench.py's N = 1 line.
+`value` is the whole-job aggregate: lattice updates of one V(3,3)-cycle over ALL slabs divided by the slowest
+rank's time.  --scaling strong swaps which leg is `value`.
 
-torch is imported BEFORE the engine on purpose: libmgpoisson.so then binds to the HIP and RCCL
-runtimes torch already loaded (same sonames) instead of bringing in a second copy.
+torch is plumbing here (process group for the rendezvous and the timing all-reduce); the engine binds to the HIP
+runtime torch brought along (one runtime per process) and resolves RCCL lazily from the copy torch has mapped.
 """
 import json
-import math
 import os
 import tempfile
 import time
@@ -39,38 +41,16 @@ def host_transport(mg, rank, world):
     mg.comm_init_host(rank, world, exchange, allgather)
 
 
-def run(args, rank, world, local_rank):
-    rehearsal = os.environ.get("MG_BENCH_TRANSPORT", "rccl") == "host"
-    if rehearsal:
-        local_rank = 0  # every rank on the one GPU
-    torch.cuda.set_device(local_rank)
-    if rehearsal:
-        dist.init_process_group(backend="gloo")
-    else:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    import multigrid_poisson_solver_amd as mg
-    from bench import grid_for, level_sizes, vcycle_algorithmic_bytes
-
-    mg.init(local_rank)
-    mg.set_smoother("stream")
-    if rehearsal:
-        host_transport(mg, rank, world)
-    else:
-        uid = [mg.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        mg.comm_init(rank, world, uid[0])
-
-    N = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n
+def run_leg(mg, args, rank, world, N, rehearsal, tmp):
+    """One timed leg: W warm-up windows, then exactly K windows back to back between barriers; max over ranks."""
+    from bench import level_sizes, vcycle_algorithmic_bytes, vcycle_compulsory_bytes
     nu = args.nu
     sizes = level_sizes(N, args.n_min)
-    tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
     cyc = os.path.join(tmp, f"Vcycle_{N}.txt")
     mg.write_vcycle_file(cyc, N, args.n_min, nu, 1e-7)
     lups = sum(2 * nu * s * s for s in sizes[:-1])
-    algo_bytes = vcycle_algorithmic_bytes(sizes, nu, nu)
-
     collapse_N = int(os.environ.get("MG_COLLAPSE_N", "1024"))
-    plan = mg.SlabPlan(cyc, world, rank, collapse_N, mixed=args.mixed)
+    plan = mg.SlabPlan(cyc, world, rank if world > 1 else -1, collapse_N, mixed=args.mixed)
     for _ in range(max(1, args.warmup)):
         r = plan.execute()
         assert r["status"] == 0, r
@@ -78,14 +58,14 @@ def run(args, rank, world, local_rank):
     plan.want_error(False)  # the analytic error is outside the reference's window (:434-445)
     dist.barrier()
     torch.cuda.synchronize()
+    mg.sync()
     mg.profile_begin(min_N=0)   # every launch and every ghost exchange of rank 0 (hipEvent pairs)
     t0 = time.perf_counter()
-    for _ in range(args.steps):   # back to back on the engine's stream, no per-step host sync
+    for _ in range(args.steps):   # back to back on the engine's streams, no per-step host sync
         plan.enqueue()
     mg.sync()
     torch.cuda.synchronize()
     dist.barrier()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = mg.profile_end()
     r = plan.collect()
@@ -94,51 +74,122 @@ def run(args, rank, world, local_rank):
     r = plan.execute()  # untimed: the result's error against the analytic solution
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
+    ms_per_step = float(t.item()) * 1e3 / args.steps
+    plan.close()
+    mg.lib().mg_pool_trim()
+    if rank != 0:
+        return None
+
+    elem = 0.5 if args.mixed else 1.0
+    is_x = lambda e: e["name"].startswith("ghost_exchange")
+    exchanges = [{"level_N": e["N"], "what": e["name"], "per_step": e["launches"] // max(1, args.steps),
+                  "avg_ms": round(e["total_ms"] / max(1, e["launches"]), 4), "bytes_per_neighbour_pair": e["algo_bytes"]}
+                 for e in sorted(prof, key=lambda e: -e["N"]) if is_x(e)]
+    launches_ms = sum(e["total_ms"] for e in prof if not is_x(e)) / max(1, args.steps)
+    exchange_ms = sum(e["total_ms"] for e in prof if is_x(e)) / max(1, args.steps)
+    per_level = {}
+    for e in prof:
+        if not is_x(e):
+            per_level[e["N"]] = per_level.get(e["N"], 0.0) + e["total_ms"] / max(1, args.steps)
+    kernels = []
+    for e in sorted((e for e in prof if e["N"] == N and not is_x(e)), key=lambda e: -e["total_ms"]):
+        avg = e["total_ms"] / max(1, e["launches"])
+        # compulsory bytes of a slab launch: the node kernel's bytes on this rank's share of the rows
+        share = 1.0 / world
+        n = float(N) * N * share
+        cb = (16.0 * n + 2.0 * n) if "restrict" in e["name"] else ((24.0 * n + 2.0 * n) if "prolong" in e["name"] else 24.0 * n)
+        kernels.append({"kernel": e["name"], "N": e["N"], "launches": e["launches"], "avg_ms": round(avg, 4),
+                        "compulsory_GBs": round(cb * elem / (avg * 1e-3) / 1e9, 1) if avg > 0 else None,
+                        "algorithmic_equiv_GBs": round(e["algo_bytes"] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None})
+    roof = None
+    if kernels:
+        k0 = kernels[0]
+        roof = {"bound": "hbm", "kernel": k0["kernel"] + " (rank 0's slab)", "achieved": k0["compulsory_GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((k0["compulsory_GBs"] or 0.0) / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_ms": k0["avg_ms"], "launches": k0["launches"],
+                "algorithmic_equiv": {"GBs": k0["algorithmic_equiv_GBs"]}}
+    cb = vcycle_compulsory_bytes(sizes) * elem
+    gbs = cb / (ms_per_step * 1e-3) / 1e9
+    return {
+        "N": N, "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+        "ms_per_step": round(ms_per_step, 4),
+        "workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
+                    f"{len(sizes)} levels, {world} row slabs, ghost rows over RCCL on a second stream (overlapped with the interior "
+                    f"rows), levels N<={collapse_N} replicated on every rank",
+        "levels": len(sizes), "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1), "mg_error": r["mg_error"],
+        "roofline": roof, "kernels": kernels[:6],
+        # where rank 0's time went (live hipEvent pairs): its kernel launches, its ghost exchanges (which
+        # include waiting for the neighbours and run beside the interior launches), the rest (gaps)
+        "rank0_ms_per_step": {"kernels": round(launches_ms, 4), "ghost_exchanges": round(exchange_ms, 4),
+                              "kernels_per_level": {str(k): round(v, 4) for k, v in sorted(per_level.items(), reverse=True)}},
+        "ghost_exchanges": exchanges,
+        "cycle_roofline": {"compulsory_bytes": cb, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                           "frac": round(gbs / (HBM_PEAK_GBS * world), 4),
+                           "algorithmic_equiv": {"bytes": vcycle_algorithmic_bytes(sizes, nu, nu)}},
+    }
+
+
+def run(args, rank, world, local_rank):
+    rehearsal = os.environ.get("MG_BENCH_TRANSPORT", "rccl") == "host"
+    if rehearsal:
+        local_rank = 0  # every rank on the one GPU
+    torch.cuda.set_device(local_rank)
+    single_process = "WORLD_SIZE" not in os.environ  # --force-slab on one rank without torchrun
+    if single_process:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if rehearsal or single_process:
+        dist.init_process_group(backend="gloo")
+        rehearsal_wire = True
+    else:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        rehearsal_wire = False
+    import multigrid_poisson_solver_amd as mg
+    from bench import STRONG_N, grid_for
+
+    mg.init(local_rank)
+    mg.set_smoother("stream")
+    if world > 1:
+        if rehearsal:
+            host_transport(mg, rank, world)
+        else:
+            uid = [mg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            mg.comm_init(rank, world, uid[0])
+
+    tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
+    N_weak = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n
+    weak = run_leg(mg, args, rank, world, N_weak, rehearsal_wire, tmp)
+    strong = None
+    if not args.no_strong and N_weak != STRONG_N:
+        strong = run_leg(mg, args, rank, world, STRONG_N, rehearsal_wire, tmp)
+    elif not args.no_strong:
+        strong = weak  # 4 GPUs: the weak-scaling grid IS 16384^2
 
     if rank == 0:
-        kernels = []
-        exchanges = [{"level_N": e["N"], "what": e["name"], "per_step": e["launches"] // max(1, args.steps),
-                      "avg_ms": round(e["total_ms"] / max(1, e["launches"]), 4), "bytes_per_neighbour_pair": e["algo_bytes"]}
-                     for e in sorted(prof, key=lambda e: -e["N"]) if e["name"].startswith("ghost_exchange")]
-        launches_ms = sum(e["total_ms"] for e in prof if not e["name"].startswith("ghost_exchange")) / max(1, args.steps)
-        exchange_ms = sum(e["total_ms"] for e in prof if e["name"].startswith("ghost_exchange")) / max(1, args.steps)
-        prof = [e for e in prof if e["N"] == N and not e["name"].startswith("ghost_exchange")]
-        for e in sorted(prof, key=lambda e: -e["total_ms"]):
-            avg = e["total_ms"] / max(1, e["launches"])
-            gbs = e["algo_bytes"] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-            kernels.append({"kernel": e["name"], "N": e["N"], "launches": e["launches"], "avg_ms": round(avg, 4),
-                            "algo_GBs": round(gbs, 1)})
-        roof = None
-        if kernels:
-            k0 = kernels[0]
-            roof = {"bound": "hbm", "kernel": k0["kernel"] + " (rank 0's slab)", "achieved": k0["algo_GBs"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k0["algo_GBs"] / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_ms": k0["avg_ms"], "launches": k0["launches"]}
-        gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9
+        head, other, name = (weak, strong, "strong_scaling")
+        if args.scaling == "strong" and strong:
+            head, other, name = (strong, weak, "weak_scaling")
         out = {
-            "metric": "vcycle_mlups", "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
-            "config": {"workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
-                                   f"{len(sizes)} levels, {world} row slabs, ghost rows over RCCL, levels N<={collapse_N} replicated on every rank",
-                       "N": N, "levels": len(sizes), "parallelism": f"slab{world}"},
-            "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
-            "mg_error": r["mg_error"],
-            "roofline": roof, "kernels": kernels[:6],
-            # where rank 0's time went (live hipEvent pairs): its kernel launches, its ghost exchanges (which
-            # include waiting for the neighbours), the rest (gaps)
-            "rank0_ms_per_step": {"kernels": round(launches_ms, 4), "ghost_exchanges": round(exchange_ms, 4)},
-            "ghost_exchanges": exchanges,
+            "metric": "vcycle_mlups", "value": head["value"], "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if head is strong and args.scaling == "strong" else "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
+            "config": {"workload": head["workload"], "N": head["N"], "levels": head["levels"], "parallelism": f"slab{world}"},
+            "fine_dof_per_s": head["fine_dof_per_s"], "mg_error": head["mg_error"], "roofline": head["roofline"],
+            "kernels": head["kernels"], "rank0_ms_per_step": head["rank0_ms_per_step"], "ghost_exchanges": head["ghost_exchanges"],
+            "cycle_roofline": head["cycle_roofline"],
             **({"transport": "host-staged over gloo, all ranks on ONE GPU: a plumbing rehearsal, not a measurement"}
-               if rehearsal else {}),
-            "cycle_roofline": {"algorithmic_bytes": algo_bytes, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS * world,
-                               "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 4)},
+               if rehearsal and world > 1 else {}),
         }
+        if other:
+            out[name] = {k: other[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
+                                               "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline")}
+            out[name]["scaling"] = "strong" if name == "strong_scaling" else "weak"
         print(json.dumps(out), flush=True)
-    plan.close()
-    mg.lib().mg_comm_finalize()
+    if world > 1:
+        mg.lib().mg_comm_finalize()
     mg.finalize()
     dist.barrier()
     dist.destroy_process_group()

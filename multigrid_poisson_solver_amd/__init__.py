@@ -8,7 +8,9 @@ device-resident arrays.  There is no CPU fallback: importing works anywhere, but
 first call raises if the library or a HIP device is missing.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -47,7 +49,7 @@ ABI = {
     "mg_get_stream": (_vp, []), "mg_sync": (None, []), "mg_last_error": (_i, []),
     "mg_last_error_string": (C.c_char_p, []), "mg_clear_error": (None, []),
     "mg_set_abort_on_error": (None, [_i]), "mg_set_smoother": (_i, [C.c_char_p]),
-    "mg_version": (C.c_char_p, []),
+    "mg_version": (C.c_char_p, []), "mg_set_source": (_i, [C.c_char_p]),
     "mg_alloc": (_vp, [_sz]), "mg_free": (None, [_vp]), "mg_pool_trim": (None, []),
     "mg_pool_bytes": (_sz, []), "mg_upload": (None, [_vp, _vp, _sz]), "mg_download": (None, [_vp, _vp, _sz]),
     "mg_copy": (None, [_vp, _vp, _sz]), "mg_fill_zero": (None, [_vp, _sz]), "mg_negate": (None, [_i, _vp]),
@@ -89,6 +91,39 @@ ABI = {
 }
 
 _lib = None
+hip_runtime = None   # which libamdhip64 the engine was bound to ("system", or the path of torch's copy)
+
+
+def _bind_hip_runtime():
+    """ONE HIP runtime per process.  libmgpoisson.so needs `libamdhip64.so.7`; a PyTorch wheel bundles its own
+    copy (soname libamdhip64.so.7, but referenced by torch under the name `libamdhip64.so`, so the loader does
+    not recognise a copy mapped earlier from /opt/rocm and maps a second one -- two runtimes on one device abort
+    at exit).  The other order is fine: once torch's copy is mapped the engine's NEEDED entry matches it by
+    soname.  So: when torch is installed but not imported yet, map ITS runtime first; every later import order
+    then ends up with that single copy.  MG_HIP_RUNTIME=system keeps the ROCm installation's runtime (for
+    processes that never import torch), MG_HIP_RUNTIME=<path> names a library explicitly."""
+    global hip_runtime
+    mode = os.environ.get("MG_HIP_RUNTIME", "auto")
+    hip_runtime = "system"
+    if mode == "system":
+        return
+    if mode not in ("auto", "torch"):
+        C.CDLL(mode, mode=C.RTLD_GLOBAL)
+        hip_runtime = mode
+        return
+    if "torch" in sys.modules:
+        hip_runtime = "torch (imported before the engine)"
+        return
+    try:
+        spec = importlib.util.find_spec("torch")  # locates the package without importing it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        hip_runtime = cand
 
 
 def load_library(path=None):
@@ -100,6 +135,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise MGError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc, gfx950).  There is no CPU fallback.")
+    _bind_hip_runtime()
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     missing = []
     for name, (res, args) in ABI.items():
@@ -160,6 +196,11 @@ def sync():
 
 def set_smoother(name):
     lib().mg_set_smoother(name.encode())
+    _check()
+
+
+def set_source(mode):
+    lib().mg_set_source(mode.encode())
     _check()
 
 

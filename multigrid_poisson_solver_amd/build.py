@@ -33,23 +33,31 @@ def _stale(target, deps):
 def ensure_built():
     """Build the in-tree library when it is absent (a source-only checkout on a box with hipcc).  One
     process at a time: the ranks of a torchrun launch serialise on a lock file."""
-    if os.path.exists(LIB):
-        return LIB
+    if os.path.exists(LIB) and not (shutil.which("hipcc") and _stale(LIB, _deps())):
+        return LIB  # up to date, or a box without hipcc (the prebuilt library is all there is)
     import fcntl
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return LIB if os.path.exists(LIB) else build()
+            return build()  # a no-op when another rank built it meanwhile
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _deps():
+    deps = _sources() + [os.path.join(CSRC, "mg_internal.h"), os.path.join(ROOT, "include", "mg_hip.h"),
+                         os.path.abspath(__file__)]
+    return deps + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+
+
 def build(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "mg_internal.h"), os.path.join(ROOT, "include", "mg_hip.h"),
-                   os.path.abspath(__file__)]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+    srcs = _sources()
+    deps = _deps()
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -65,9 +73,8 @@ def build(force=False, verbose=False):
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True)
             objs.append(o)
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs + ["-lpthread"]
-        if os.path.exists(os.path.join(CSRC, "mg_comm.cpp")):
-            cmd += ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        # RCCL is resolved with dlopen on the first communicator call (mg_comm.cpp): no -lrccl here
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

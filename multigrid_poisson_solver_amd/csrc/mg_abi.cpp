@@ -251,7 +251,7 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         return;
     }
 
-    const bool stream = c.smoother == SMOOTHER_STREAM && k::stream_supported(N);
+    const bool stream = c.smoother != SMOOTHER_SIMPLE && k::stream_supported(N);
     // sweeps per launch: the streaming kernel advances up to stream_max_steps() time
     // levels per pass over HBM, the simple kernel one.  The launch count is made odd so
     // that, ping-ponging between U_out and one partner buffer, the last launch lands in
@@ -275,12 +275,12 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         // odd count: dst alternates so that the last is U_out.  even count (own partner):
         // start in the partner, the last launch then lands in U_out as well.
         double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
-        const bool plain_single = stream && take == 1 && src && !(i == 0 && fu.coarse) && !(last && (D_out || fu.Fc || error_dev)) &&
+        const bool plain_single = stream && c.smoother != SMOOTHER_STREAM_ONLY && take == 1 && src && !(i == 0 && fu.coarse) && !(last && (D_out || fu.Fc || error_dev)) &&
                                   N >= 2048 && N % 2 == 0;
         if (plain_single) {
             // one bare sweep of a large grid: the one-row-per-block pair kernel is the faster of the two
             // (5.1 vs 4.5 TB/s at N = 8192; same bits) -- there is nothing to fuse and no row history to amortise
-            ProfScope ps("jacobi_simple", N, (double)n * 24.0);
+            ProfScope ps("jacobi_pair", N, (double)n * 24.0);
             k::jacobi_simple(s, N, dx2, src, F, dst);
         } else if (stream) {
             // algorithmic bytes: 24 B per sweep and point, + 8 for a folded
@@ -297,7 +297,8 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
             k::jacobi_stream(s, N, dx2, inv, src, F, dst, take, last ? error_dev : nullptr, last ? D_out : nullptr,
                              d_sign, pro ? fu.coarse : nullptr, fu.Nc, fu.pt, rst ? fu.Fc : nullptr, fu.M, fu.rt);
         } else {
-            ProfScope ps(src ? "jacobi_simple" : "jacobi_simple<zero>", N, (double)n * (src ? 24.0 : 32.0));
+            // (k_jacobi_pair on even N, k_jacobi_simple on odd N: the launcher picks)
+            ProfScope ps(src ? (N % 2 == 0 && N >= 512 ? "jacobi_pair" : "jacobi_simple") : "jacobi_simple<zero>", N, (double)n * (src ? 24.0 : 32.0));
             k::jacobi_simple(s, N, dx2, src, F, dst);
         }
         src = dst;
@@ -351,6 +352,8 @@ int mg_init(int device)
     c.ready = true;
     const char *sm = getenv("MG_SMOOTHER");
     if (sm && *sm) mg_set_smoother(sm);
+    const char *src = getenv("MG_SOURCE");
+    if (src && *src) mg_set_source(src);
     return 0;
 }
 
@@ -427,8 +430,19 @@ int mg_set_smoother(const char *name)
 {
     if (name && strcmp(name, "stream") == 0) ctx().smoother = SMOOTHER_STREAM;
     else if (name && strcmp(name, "simple") == 0) ctx().smoother = SMOOTHER_SIMPLE;
+    else if (name && strcmp(name, "stream_only") == 0) ctx().smoother = SMOOTHER_STREAM_ONLY;
     else {
-        fail(MG_ERR_ARG, "mg_set_smoother: unknown smoother '%s' (stream|simple)", name ? name : "(null)");
+        fail(MG_ERR_ARG, "mg_set_smoother: unknown smoother '%s' (stream|simple|stream_only)", name ? name : "(null)");
+        return 1;
+    }
+    return 0;
+}
+int mg_set_source(const char *name)
+{
+    if (name && strcmp(name, "host") == 0) ctx().source_on_device = false;
+    else if (name && strcmp(name, "device") == 0) ctx().source_on_device = true;
+    else {
+        fail(MG_ERR_ARG, "mg_set_source: unknown mode '%s' (host|device)", name ? name : "(null)");
         return 1;
     }
     return 0;
@@ -515,20 +529,47 @@ namespace mg {
 void fill_source_rows(int N, double L, double min_x, double min_y, int row_lo, int row_hi, double *dev_dst)
 {
     if (row_hi <= row_lo) return;
-    const size_t n = (size_t)(row_hi - row_lo) * N;
-    double *host = nullptr;
-    if (!MG_HIP(hipHostMalloc((void **)&host, n * sizeof(double), hipHostMallocDefault))) return;
-    // the job indexes rows globally; shift the destination so row row_lo lands at host[0]
-    SourceJob job{N, L / (double)(N - 1), min_x, min_y, host - (size_t)row_lo * N};
-    struct Range { SourceJob *j; int lo; } rg{&job, row_lo};
-    parallel_for((size_t)(row_hi - row_lo),
-                 [](size_t a, size_t b, void *arg) {
-                     Range *r = (Range *)arg;
-                     source_rows(a + r->lo, b + r->lo, r->j);
-                 },
-                 &rg);
-    mg_upload(dev_dst, host, n);
-    (void)hipHostFree(host);
+    Context &c = ctx();
+    if (c.source_on_device) {  // mg_set_source("device"): no host pass, no PCIe; F within 2 ulp of the host form
+        k::source_device(c.stream, N, L, dev_dst, min_x, min_y, row_lo, row_hi);
+        return;
+    }
+    // The host evaluates (libm exp: the reference's bits) into two pinned staging buffers of at most 128 MiB
+    // each and uploads chunk by chunk: while chunk i travels, chunk i+1 is computed.  The 8 GiB source of
+    // N = 32768 therefore needs 256 MiB of pinned memory, not 8 GiB.
+    const size_t row_bytes = (size_t)N * sizeof(double);
+    size_t chunk_rows = ((size_t)128 << 20) / row_bytes;
+    if (chunk_rows < 1) chunk_rows = 1;
+    if (chunk_rows > (size_t)(row_hi - row_lo)) chunk_rows = (size_t)(row_hi - row_lo);
+    double *stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    const int nbuf = chunk_rows < (size_t)(row_hi - row_lo) ? 2 : 1;
+    bool ok = true;
+    for (int b = 0; b < nbuf && ok; ++b)
+        ok = MG_HIP(hipHostMalloc((void **)&stage[b], chunk_rows * row_bytes, hipHostMallocDefault)) && MG_HIP(hipEventCreate(&done[b]));
+    int b = 0;
+    for (int r0 = row_lo; r0 < row_hi && ok; r0 += (int)chunk_rows, b = (b + 1) % nbuf) {
+        const int r1 = r0 + (int)chunk_rows < row_hi ? r0 + (int)chunk_rows : row_hi;
+        if (r0 >= row_lo + nbuf * (int)chunk_rows) ok = MG_HIP(hipEventSynchronize(done[b]));  // the buffer's last upload
+        if (!ok) break;
+        // the job indexes rows globally; shift the destination so row r0 lands at stage[b][0]
+        SourceJob job{N, L / (double)(N - 1), min_x, min_y, stage[b] - (size_t)r0 * N};
+        struct Range { SourceJob *j; int lo; } rg{&job, r0};
+        parallel_for((size_t)(r1 - r0),
+                     [](size_t a, size_t e, void *arg) {
+                         Range *r = (Range *)arg;
+                         source_rows(a + r->lo, e + r->lo, r->j);
+                     },
+                     &rg, 16);
+        ok = MG_HIP(hipMemcpyAsync(dev_dst + (size_t)(r0 - row_lo) * N, stage[b], (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice,
+                                   c.stream)) &&
+             MG_HIP(hipEventRecord(done[b], c.stream));
+    }
+    (void)hipStreamSynchronize(c.stream);
+    for (int i = 0; i < 2; ++i) {
+        if (stage[i]) (void)hipHostFree(stage[i]);
+        if (done[i]) (void)hipEventDestroy(done[i]);
+    }
 }
 
 // one fused launch on a row window (slab mode supports step <= stream_max_steps(): a second
@@ -617,18 +658,8 @@ extern "C" {
 void mg_getSource(int N, double L, double *F, double min_x, double min_y)
 {
     if (!require_ready("mg_getSource") || !grid_args_ok("mg_getSource", N)) return;
-    const char *mode = getenv("MG_SOURCE");
-    if (mode && strcmp(mode, "device") == 0) {  // <= 1 ulp from libm, no host pass
-        k::source_device(ctx().stream, N, L, F, min_x, min_y);
-        return;
-    }
-    const size_t n = (size_t)N * N;
-    double *host = nullptr;
-    if (!MG_HIP(hipHostMalloc((void **)&host, n * sizeof(double), hipHostMallocDefault))) return;
-    SourceJob job{N, L / (double)(N - 1), min_x, min_y, host};
-    parallel_for((size_t)N, source_rows, &job);
-    mg_upload(F, host, n);
-    (void)hipHostFree(host);
+    // host libm through chunked pinned staging (the reference's bits), or k_source after mg_set_source("device")
+    fill_source_rows(N, L, min_x, min_y, 0, N, F);
 }
 
 void mg_getAnalytic(int N, double L, double *U, double min_x, double min_y)
@@ -686,7 +717,7 @@ void mg_smooth_restrict(int N, double L, const double *U_in, double *U_out, doub
     Context &c = ctx();
     const RestrictTable &rt = restrict_table(N, M);
     if (!rt.lo) return;
-    if (step > 0 && c.smoother == SMOOTHER_STREAM && k::stream_fusable(N) && rt.fusable) {
+    if (step > 0 && c.smoother != SMOOTHER_SIMPLE && k::stream_fusable(N) && rt.fusable) {
         Fusion fu;
         fu.Fc = F_c;
         fu.M = M;
@@ -721,7 +752,7 @@ void mg_prolong_smooth(int Nc, const double *U_c, int N, double L, const double 
     Context &c = ctx();
     const ProlongTable &pt = prolong_table(Nc, N);
     if (!pt.owner_row) return;
-    if (step > 0 && c.smoother == SMOOTHER_STREAM && k::stream_fusable(N) && pt.fusable) {
+    if (step > 0 && c.smoother != SMOOTHER_SIMPLE && k::stream_fusable(N) && pt.fusable) {
         Fusion fu;
         fu.coarse = U_c;
         fu.Nc = Nc;
@@ -892,7 +923,10 @@ void mg_doSmoothing(int N, double L, double *U, double *F, int step, double *err
         // in-place semantics of the reference on top of the out-of-place kernels:
         // sweep into pool scratch, then hand the result back into U
         double *tmp = (double *)scratch_pool().get(n * sizeof(double));
-        if (!tmp) return;
+        if (!tmp) {
+            c.defer_norms = deferred;
+            return;
+        }
         smooth_pp(N, L, U, tmp, F, step, error ? slot : nullptr, nullptr, +1);
         MG_HIP(hipMemcpyAsync(U, tmp, n * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
         scratch_pool().put(tmp);  // stream-ordered reuse: later users enqueue behind the copy

@@ -14,8 +14,15 @@
 // rank-mode driver -- counts, peers, grouping, the collapse all-gather -- can be run by several
 // processes on ONE GPU box and compared with the oracle, which RCCL (one rank per device) cannot
 // do there.  It moves ghost rows only; all arithmetic stays on the device.
+//
+// RCCL is NOT a link-time dependency of the engine: its entry points are resolved with dlopen on the
+// first communicator call.  A single-GPU user never maps it, and a process that already carries a copy
+// (PyTorch bundles its own librccl.so) reuses THAT copy instead of mapping a second RCCL/HIP runtime
+// next to it (two runtimes in one process abort at exit).  <rccl/rccl.h> is included for its types only.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -26,6 +33,74 @@ namespace mg {
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_nranks = 1;
+
+// ---- RCCL entry points, resolved lazily -------------------------------------------------------
+struct Rccl {
+    void *handle = nullptr;
+    bool tried = false;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string where;
+} g_rccl;
+
+// order: MG_RCCL_LIB (explicit path), a copy this process has mapped already (RTLD_NOLOAD matches by
+// soname, so torch's bundled "librccl.so" with soname librccl.so.1 is found), the loader's search
+// path, the ROCm installation
+bool rccl_load()
+{
+    Rccl &r = g_rccl;
+    if (r.handle) return true;
+    if (r.tried) return false;
+    r.tried = true;
+    std::vector<std::pair<std::string, int>> cand;
+    if (const char *e = getenv("MG_RCCL_LIB")) cand.emplace_back(e, RTLD_NOW | RTLD_GLOBAL);
+    cand.emplace_back("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    cand.emplace_back("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    cand.emplace_back("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (const char *e = getenv("ROCM_PATH")) cand.emplace_back(std::string(e) + "/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    cand.emplace_back("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    for (const auto &c : cand) {
+        r.handle = dlopen(c.first.c_str(), c.second);
+        if (r.handle) {
+            r.where = c.first + ((c.second & RTLD_NOLOAD) ? " (already mapped)" : "");
+            break;
+        }
+    }
+    if (!r.handle) {
+        fail(MG_ERR_COMM, "RCCL is not available: dlopen(librccl.so.1) failed (%s); set MG_RCCL_LIB", dlerror());
+        return false;
+    }
+    bool ok = true;
+    auto sym = [&](const char *name) {
+        void *p = dlsym(r.handle, name);
+        if (!p) ok = false;
+        return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        fail(MG_ERR_COMM, "RCCL library %s lacks a required entry point", r.where.c_str());
+        dlclose(r.handle);
+        r.handle = nullptr;
+        return false;
+    }
+    if (getenv("MG_COMM_DEBUG")) fprintf(stderr, "[mg_comm] RCCL from %s\n", r.where.c_str());
+    return true;
+}
 
 // host-staged transport
 mg_host_transport g_host = {};
@@ -74,7 +149,7 @@ void host_flush()
 bool nccl_ok(ncclResult_t r, const char *what)
 {
     if (r == ncclSuccess) return true;
-    fail(MG_ERR_COMM, "RCCL call failed: %s -> %s", what, ncclGetErrorString(r));
+    fail(MG_ERR_COMM, "RCCL call failed: %s -> %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return false;
 }
 #define MG_NCCL(expr) nccl_ok((expr), #expr)
@@ -92,7 +167,7 @@ void comm_group_begin()
         ++g_group_depth;
         return;
     }
-    MG_NCCL(ncclGroupStart());
+    MG_NCCL(g_rccl.GroupStart());
 }
 void comm_group_end()
 {
@@ -100,7 +175,7 @@ void comm_group_end()
         if (--g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(ncclGroupEnd());
+    MG_NCCL(g_rccl.GroupEnd());
 }
 
 void comm_send(const void *buf, size_t bytes, int peer)
@@ -111,7 +186,7 @@ void comm_send(const void *buf, size_t bytes, int peer)
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(ncclSend(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.Send(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
 }
 void comm_recv(void *buf, size_t bytes, int peer)
 {
@@ -121,7 +196,7 @@ void comm_recv(void *buf, size_t bytes, int peer)
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(ncclRecv(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.Recv(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
 }
 void comm_allgather(const double *send, double *recv, size_t count_per_rank)
 {
@@ -137,7 +212,7 @@ void comm_allgather(const double *send, double *recv, size_t count_per_rank)
         (void)MG_HIP(hipMemcpy(recv, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
         return;
     }
-    MG_NCCL(ncclAllGather(send, recv, count_per_rank, ncclDouble, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, g_comm, ctx().stream));
 }
 
 }  // namespace mg
@@ -151,7 +226,7 @@ int mg_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
 int mg_comm_get_unique_id(void *out)
 {
     ncclUniqueId id;
-    if (!MG_NCCL(ncclGetUniqueId(&id))) return 1;
+    if (!rccl_load() || !MG_NCCL(g_rccl.GetUniqueId(&id))) return 1;
     memcpy(out, &id, sizeof id);
     return 0;
 }
@@ -167,7 +242,7 @@ int mg_comm_init(int rank, int nranks, const void *unique_id)
     }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    if (!MG_NCCL(ncclCommInitRank(&g_comm, nranks, id, rank))) return 1;
+    if (!rccl_load() || !MG_NCCL(g_rccl.CommInitRank(&g_comm, nranks, id, rank))) return 1;
     g_rank = rank;
     g_nranks = nranks;
     return 0;
@@ -198,7 +273,7 @@ void mg_comm_finalize(void)
     g_ops.clear();
     if (g_comm) {
         (void)hipStreamSynchronize(ctx().stream);
-        (void)ncclCommDestroy(g_comm);
+        (void)g_rccl.CommDestroy(g_comm);
         g_comm = nullptr;
     }
     g_rank = 0;

@@ -396,6 +396,7 @@ bool try_tail(Exec &x)
     size_t tok = x.tok;
     if (!scan_tail(p->tokens, &tok, p->sizes, x.at, p->con_step, top->N, p->L, &a, node_level)) return false;
     const int n_nodes = a.n_nodes;
+    if (p->records.size() + (size_t)n_nodes > p->err_cap) return false;  // (cannot happen: err_cap counts every node token)
     // records + report, in the order the per-node interpreter would emit them
     const char *down = "             *\n             |\n Restriction |\n             |\n             *\n";
     const char *up = "             *\n             |\nProlongation |\n             |\n             *\n";
@@ -478,6 +479,7 @@ void run_nodes(Exec &x)
         if (!x.next_int(&node)) break;  // end of file without a 2
         if (node == 2) break;           // :162-164
         if (x.c.last_error) { x.status = 10; break; }
+        if (p->records.size() >= p->err_cap) { x.status = 11; break; }  // error slots exhausted (as the slab driver)
 
         if (node == -1) {  // :169-300
             int step = 0, next_N = 0;
@@ -704,10 +706,12 @@ mg_cycle_plan *mg_cycle_load(const char *path, int flags)
     } else if (p->con_N == 2) {  // :132-146
         for (int n = p->N_max; n >= p->N_min; --n) p->sizes.push_back(n);
     }
-    size_t smoothing_nodes = 0;
+    // one error slot per record; every -1, 0 and 1 node adds at most one record (operands that happen to
+    // equal a node code only over-count), so the slots cannot run out
+    size_t nodes = 0;
     for (double t : p->tokens)
-        if (t == -1.0 || t == 1.0) ++smoothing_nodes;
-    p->err_cap = smoothing_nodes + 8;
+        if (t == -1.0 || t == 1.0 || t == 0.0) ++nodes;
+    p->err_cap = nodes + 8;
     p->err_dev = (double *)p->pool.get(p->err_cap * sizeof(double));
     const bool mixed = (flags & MG_CYCLE_MIXED) != 0;
     if (mixed && (!(flags & MG_CYCLE_FUSED) || p->con_N != 1 || p->con_step < 1 || p->con_step > k::stream_max_steps())) {

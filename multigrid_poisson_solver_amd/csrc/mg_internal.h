@@ -78,7 +78,9 @@ private:
     size_t held_ = 0;
 };
 
-enum Smoother { SMOOTHER_STREAM = 0, SMOOTHER_SIMPLE = 1 };
+// STREAM_ONLY: the streaming kernel also for a bare single sweep of a large grid (which STREAM hands to the
+// one-row-per-block pair kernel): lets the bench report the S = 1 streaming kernel's own rate
+enum Smoother { SMOOTHER_STREAM = 0, SMOOTHER_SIMPLE = 1, SMOOTHER_STREAM_ONLY = 2 };
 
 struct Context {
     bool ready = false;
@@ -89,6 +91,7 @@ struct Context {
     Pool pool;
     Pool *active_pool = nullptr;           // plan-private arena while a cycle plan executes
     Smoother smoother = SMOOTHER_STREAM;
+    bool source_on_device = false;         // mg_set_source("device"): getSource evaluated by k_source
     // reduction scratch: per-block partial sums + scalar slots
     double *partials = nullptr;
     size_t partials_cap = 0;
@@ -169,7 +172,7 @@ void comm_recv(void *buf, size_t bytes, int peer);
 void comm_allgather(const double *send, double *recv, size_t count_per_rank);
 
 // small host helper: run fn(begin,end) over [0,n) on the host threads
-void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg);
+void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg, size_t serial_below = 4096);
 
 // ---------------------------------------------------------------------------
 // kernel launchers (mg_kernels.hip).  All enqueue on s and return immediately.
@@ -217,7 +220,8 @@ void refine_residual_rows(hipStream_t s, int N, double inv, const double *U, con
                           double *out_raw);
 void add(hipStream_t s, size_t n, double *a, const double *b);
 void negate(hipStream_t s, size_t n, double *a);
-void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y);
+// F points at row row_lo; rows [row_lo, row_hi)
+void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y, int row_lo, int row_hi);
 void analytic(hipStream_t s, int N, double L, double *U, double min_x, double min_y);
 void analytic_error(hipStream_t s, int N, double L, const double *U, double min_x, double min_y, double *out);
 // raw sum |analytic - U| over the owned rows of a row window (combined across slabs by the caller)

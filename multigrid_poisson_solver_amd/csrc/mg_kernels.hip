@@ -325,16 +325,17 @@ __global__ __launch_bounds__(TB) void k_to_f64(double *__restrict__ dst, const f
 // ---------------------------------------------------------------- problem definition
 // src/MG_solver_CPU.cpp:488 / :544.  Device exp() is within 1 ulp of libm's, so these
 // are NOT bit-identical to the host evaluation; the driver uses the host form for F.
-__global__ __launch_bounds__(TB) void k_source(int N, double h, double *__restrict__ F, double min_x, double min_y)
+// F points at grid row row0 (row slabs evaluate their own window)
+__global__ __launch_bounds__(TB) void k_source(int N, double h, double *__restrict__ F, double min_x, double min_y, int row0)
 {
-    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y;
+    const int c = blockIdx.x * TB + threadIdx.x, r = blockIdx.y + row0;
     if (c >= N) return;
     double v = 0.0;
     if (!rim(r, c, N)) {
         const double x = (double)c * h + min_x, y = (double)r * h + min_y;
         v = 2.0 * x * (y - 1) * (y - 2.0 * x + x * y + 2.0) * exp(x - y);
     }
-    F[(size_t)r * N + c] = v;
+    F[(size_t)blockIdx.y * N + c] = v;
 }
 __device__ __forceinline__ double analytic_at(int r, int c, int N, double h, double min_x, double min_y)
 {
@@ -678,9 +679,11 @@ void negate(hipStream_t s, size_t n, double *a)
     hipLaunchKernelGGL(k_negate, dim3(grid_flat(n)), dim3(TB), 0, s, n, a);
 }
 
-void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y)
+void source_device(hipStream_t s, int N, double L, double *F, double min_x, double min_y, int row_lo, int row_hi)
 {
-    hipLaunchKernelGGL(k_source, dim3((N + TB - 1) / TB, N), dim3(TB), 0, s, N, L / (double)(N - 1), F, min_x, min_y);
+    if (row_hi <= row_lo) return;
+    hipLaunchKernelGGL(k_source, dim3((N + TB - 1) / TB, row_hi - row_lo), dim3(TB), 0, s, N, L / (double)(N - 1), F, min_x, min_y,
+                       row_lo);
 }
 void analytic(hipStream_t s, int N, double L, double *U, double min_x, double min_y)
 {

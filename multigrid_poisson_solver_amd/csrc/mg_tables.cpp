@@ -167,12 +167,12 @@ const ProlongTable &prolong_table(int N, int M)
     return c.ptab.emplace(key, t).first->second;
 }
 
-void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg)
+void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg, size_t serial_below)
 {
     unsigned hw = std::thread::hardware_concurrency();
     size_t nt = hw ? hw : 4;
     if (nt > 64) nt = 64;
-    if (n < 4096 || nt == 1) {
+    if (n < serial_below || nt == 1) {
         fn(0, n, arg);
         return;
     }

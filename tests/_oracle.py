@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libmgoracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libmgref.so")
+REF_SO_MAKEFLAGS = os.path.join(ORACLE_DIR, "_ref", "libmgref_makeflags.so")  # src/Makefile:8 flags (no -O)
 REF_EXE = os.path.join(ORACLE_DIR, "_ref", "MG_CPU_ref")
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -157,8 +158,8 @@ class Oracle(_Operators):
 class Reference(_Operators):
     """The reference's own operators, compiled from /root/reference by oracle/Makefile."""
 
-    def __init__(self):
-        lib = C.CDLL(REF_SO)
+    def __init__(self, makefile_flags=False):
+        lib = C.CDLL(REF_SO_MAKEFLAGS if makefile_flags else REF_SO)
         super().__init__(lib, "ref_")
 
     def set_threads(self, n):

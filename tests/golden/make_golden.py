@@ -7,7 +7,8 @@ reference's outputs), the reference source never enters this repository.
     python tests/golden/make_golden.py [--big]
 
 --big additionally regenerates golden_fullsize.json (checksums of reference outputs at
-N = 8192 .. 32768; needs ~12 GiB of RAM and a few minutes).
+N = 4096 .. 32768; needs ~12 GiB of RAM and a few minutes); --add-16384 only adds the
+smoothing/residual checksums at N = 16384 to the existing file.
 """
 import json
 import os
@@ -125,10 +126,10 @@ def level_tables(orc):
     return out
 
 
-def fullsize(ref):
+def fullsize(ref, smoothing_sizes=(4096, 8192, 16384), transfer_sizes=(8192, 16384, 32768)):
     """checksums of REFERENCE outputs on hash-generated inputs at benchmark sizes."""
     out = {}
-    for N in (4096, 8192):
+    for N in smoothing_sizes:
         U = _synth.hash_field(N, 11)
         F = _synth.hash_field(N, 22)
         U3, e = ref.doSmoothing(N, 1.0, U, F, 3)
@@ -136,7 +137,7 @@ def fullsize(ref):
         out[f"residual_N{N}"] = {"checksum": _synth.checksum(ref.getResidual(N, 1.0, U, F))}
         del U3, F
         print("smoothing/residual", N, flush=True)
-    for N in (8192, 16384, 32768):
+    for N in transfer_sizes:
         M = N // 2
         Uf = _synth.hash_field(N, 33)
         out[f"restrict_{N}to{M}"] = {"checksum": _synth.checksum(ref.doRestriction(N, Uf, M))}
@@ -151,6 +152,14 @@ def fullsize(ref):
 def main():
     o.build_oracle()
     orc, ref = o.Oracle(), o.Reference()
+    if "--add-16384" in sys.argv:  # only the smoothing/residual checksums at N = 16384 (configs 4/5), merged into the file
+        path = os.path.join(HERE, "golden_fullsize.json")
+        with open(path) as f:
+            have = json.load(f)
+        have.update(fullsize(ref, smoothing_sizes=(16384,), transfer_sizes=()))
+        with open(path, "w") as f:
+            json.dump(have, f, indent=1)
+        return
     ops = per_op_vectors(ref)
     e2e_arrays, reports = end_to_end(orc, ref)
     np.savez_compressed(os.path.join(HERE, "golden_ops.npz"), **ops)

@@ -159,6 +159,23 @@ def test_manual_grammar_con_step0_con_N0_and_minus_one(mg, oracle, tmp_path):
             plan.close()
 
 
+@pytest.mark.parametrize("name", ["StepZero.txt", "StepZeroHalving.txt"])
+def test_step_zero_nodes_vs_oracle(mg, oracle, cycle_dir, name):
+    """SURVEY.md section 8 row D6 (src/MG_solver_CPU.cpp:241-243, :296-299, :409-411): a 0-step `-1` node does
+    nothing (no smoothing, no push; with con_N = 1 it still advances the size walk), a 0-step `1` node prolongs
+    and adds without smoothing.  The oracle's handling is pinned to the reference program on these two files in
+    tests/test_oracle_pin.py."""
+    path = os.path.join(cycle_dir, name)
+    want = oracle.run_cycle_file(path)
+    assert want["status"] == 0
+    for fused, graph in ((False, False), (True, False), (True, True)):
+        plan = mg.CyclePlan(path, fused=fused, graph=graph)
+        for _ in range(3 if graph else 1):
+            got = plan.execute(fetch_U=True)
+        check_against(got, want, zero_sign=fused)
+        plan.close()
+
+
 def test_malformed_cycle_files(mg, oracle, tmp_path):
     # more -1 nodes than generated sizes: the reference reads out of bounds (SURVEY D2);
     # both drivers report status 4 instead

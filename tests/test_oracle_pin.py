@@ -151,7 +151,8 @@ def test_oracle_driver_vs_reference_program(oracle, reference, cycle_dir, tmp_pa
     """The reference PROGRAM (oracle/_ref/MG_CPU_ref) on the shipped cycle files: same
     printed report, same CSV, and the reference operators under the oracle driver give the
     same U bit for bit."""
-    for name in ["test.txt", "Vcycle.txt", "VcycleTrigger.txt", "Wcycle.txt"]:
+    # the four shipped files + the two step-0 files of SURVEY.md section 8 row D6 (tests/_cycles.py:EXTRA)
+    for name in ["test.txt", "Vcycle.txt", "VcycleTrigger.txt", "Wcycle.txt", "StepZero.txt", "StepZeroHalving.txt"]:
         shutil.copy(os.path.join(cycle_dir, name), tmp_path)
         stdout = subprocess.run([_oracle.REF_EXE, "2", name], cwd=tmp_path, capture_output=True, text=True, check=True).stdout
         body = "".join(l for l in stdout.splitlines(keepends=True)

@@ -3,6 +3,8 @@ Bar (BASELINE.json north_star): restriction/prolongation indexing bit-exact; her
 output ARRAY is asserted bit-exact (the kernels keep the reference's evaluation order and
 are built with -ffp-contract=off); scalar norms, whose summation order is unspecified even
 in the reference (OpenMP reduction), are held to 1e-12 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -298,6 +300,21 @@ def test_engine_on_a_torch_stream_and_tensors():
     assert out.returncode == 0 and "TORCH_INTEROP OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+def test_engine_loaded_before_torch_exits_cleanly():
+    """The other import order: the engine is loaded and used FIRST, torch is imported afterwards, the engine
+    then works on torch tensors, and the process must end with exit code 0 with ONE HIP runtime mapped.
+    (libmgpoisson.so no longer links RCCL -- it is resolved lazily inside mg_comm_init -- and the Python binding
+    maps the installed torch wheel's own libamdhip64 before the engine, see _bind_hip_runtime; both used to be
+    second copies of runtimes torch brings along, and two runtimes on one device abort at exit.)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k != "MG_HIP_RUNTIME"}
+    out = subprocess.run([sys.executable, os.path.join(here, "_engine_first_worker.py")], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0 and "ENGINE_FIRST OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ synthetic data
 def test_synthetic_fill_and_checksum(mg):
     for N, seed in ((64, 11), (257, 22)):
@@ -310,17 +327,66 @@ def test_synthetic_fill_and_checksum(mg):
 
 
 # ------------------------------------------------------------------ full benchmark sizes
-@pytest.mark.parametrize("N", [4096, 8192])
+@pytest.mark.parametrize("N", [4096, 8192, 16384])
 def test_fullsize_smoothing_and_residual_checksums(mg, golden_fullsize, smoother, N):
-    """BASELINE.json sizes: inputs are hash-generated on the device, the outputs' 128-bit
-    checksums must equal those of the REFERENCE's doSmoothing/getResidual on the same
-    inputs (tests/golden/make_golden.py --big)."""
+    """BASELINE.json sizes (16384: the finest grid of configs 4 and 5): inputs are hash-generated on the
+    device, the outputs' 128-bit checksums must equal those of the REFERENCE's doSmoothing/getResidual
+    on the same inputs (tests/golden/make_golden.py --big / --add-16384)."""
     U, F, D = mg.DeviceGrid.uniform(N, 11), mg.DeviceGrid.uniform(N, 22), mg.DeviceGrid(N)
     mg.getResidual(N, 1.0, U, F, D)
     assert list(D.checksum()) == golden_fullsize[f"residual_N{N}"]["checksum"]
     err = mg.doSmoothing(N, 1.0, U, F, 3)
     assert list(U.checksum()) == golden_fullsize[f"smooth3_N{N}"]["checksum"]
     assert err == pytest.approx(golden_fullsize[f"smooth3_N{N}"]["error"], rel=REL)
+    for g in (U, F, D):
+        g.free()
+    mg.lib().mg_pool_trim()
+
+
+def ulp_distance(a, b):
+    """distance in units in the last place between two fp64 arrays of the same sign pattern"""
+    ia, ib = a.view(np.int64), b.view(np.int64)
+    ia = np.where(ia < 0, np.int64(-2 ** 63) - ia, ia)  # map the sign-magnitude bit patterns onto a number line
+    ib = np.where(ib < 0, np.int64(-2 ** 63) - ib, ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("N", [64, 257, 2048])
+def test_device_source_within_two_ulp_of_the_host_form(mg, oracle, N):
+    """SURVEY.md section 8 row (f-1), src/MG_solver_CPU.cpp:468-493 (GPU twin MG_solver_GPU.cu:502-528):
+    mg_set_source("device") evaluates F with k_source -- no host pass, no PCIe.  The device exp() is within
+    1 ulp of libm's and one more rounding follows (the product with the polynomial factor), so F is within
+    2 ulp of the host form, which is the reference's bit for bit; the rim is exactly 0 in both."""
+    host = mg.getSource(N, 1.5, 0.25, -0.5).to_host()
+    assert_bits(host, oracle.getSource(N, 1.5, 0.25, -0.5), "host getSource == reference getSource")
+    mg.set_source("device")
+    try:
+        dev = mg.getSource(N, 1.5, 0.25, -0.5).to_host()
+    finally:
+        mg.set_source("host")
+    assert np.array_equal(dev[0], host[0]) and np.array_equal(dev[:, -1], host[:, -1])
+    d = ulp_distance(dev, host)
+    assert d.max() <= 2, f"device source is {d.max()} ulp from the host form"
+
+
+def test_cycle_with_device_source(mg, oracle, cycle_dir):
+    """The same row end to end: a V-cycle whose F comes from k_source.  Results are no longer bit-comparable
+    with the reference (F moved by <= 2 ulp); the final error against the analytic solution agrees to 1e-9
+    relative and every smoothing error to 1e-10 -- the bound the header states for this mode."""
+    path = os.path.join(cycle_dir, "Vcycle.txt")
+    want = oracle.run_cycle_file(path)
+    mg.set_source("device")
+    try:
+        plan = mg.CyclePlan(path, fused=True)
+        got = plan.execute(fetch_U=True)
+        plan.close()
+    finally:
+        mg.set_source("host")
+    assert got["status"] == 0
+    assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-9)
+    for g, w in zip(got["records"], want["records"]):
+        assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-10, abs=1e-300)
+    np.testing.assert_allclose(got["U"], want["U"], rtol=1e-10, atol=1e-18)
 
 
 @pytest.mark.parametrize("N", [8192, 16384, 32768])

@@ -157,6 +157,30 @@ def test_rank_mode_over_host_transport(mg, oracle, tmp_path, world, N, collapse,
     assert f"SLAB_HOST_TRANSPORT OK {world} {N} {collapse}" in out.stdout
 
 
+def test_bench_self_launches_its_ranks(mg):
+    """`python3 bench.py --gpus 2` outside torchrun must start its two ranks itself (a child torch.distributed.run,
+    before the parent touches the GPU) and relay rank 0's ONE JSON line: the shape of the command the driver uses
+    for the scaling run.  Two RCCL ranks cannot share this box's one GPU, so the wire is the host-staged
+    rehearsal transport; the line must carry both legs (weak = `value`, strong = N 16384^2)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MG_SLAB_POISON")}
+    env.update(MG_BENCH_TRANSPORT="host", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["metric"] == "vcycle_mlups" and line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["N"] == 11520 and line["value"] > 0
+    assert line["strong_scaling"]["N"] == 16384 and line["strong_scaling"]["value"] > 0
+    assert line["mg_error"] == pytest.approx(0.000883, abs=2e-6)          # the V(3,3) result at this resolution
+    assert line["strong_scaling"]["mg_error"] == pytest.approx(0.000883, abs=2e-6)
+
+
 def test_fresh_slab_arrays_are_poisoned(mg, tmp_path):
     """conftest sets MG_SLAB_POISON: the rows of a slab array that nobody has written are NaN, so a
     missing halo row cannot hide behind stale data in the parity tests above."""
