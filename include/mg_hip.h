@@ -256,11 +256,21 @@ int  mg_comm_size(void);
  * is collapsed (replicated whole on every rank; reported as [0, N) for rank 0 and [0, 0) for the
  * others).  Returns the number of levels. */
 int  mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out, int *collapsed_out);
+/* a level stays distributed while every slab keeps at least 2 * mg_slab_ghost_rows() rows */
 int  mg_slab_ghost_rows(void);
-/* host-only: ghost rows of each level that actually travel in an exchange (what the level's launches read beyond
- * the owned rows; 0 for collapsed levels), for `steps` sweeps per node.  Returns the number of levels, -1 when
- * the halo cannot hold the hierarchy. */
-int  mg_slab_ghost_depths(int N_max, int N_min, int nranks, int collapse_N, int steps, int *out);
+/* host-only: the communication-avoiding schedule mg_slab_load derives for a hierarchy (`steps` sweeps per node).
+ * Per distributed level and rank: own = owned rows; dext = rows its `-1` launch updates (owned rows + the rows whose
+ * restricted residual is the next level's F halo, recomputed instead of exchanged); ext = rows its `1` launch updates
+ * (owned rows + what the next finer level's prolongation reads); fwr = rows of the level's F the finer level's launch
+ * writes.  Per level: halo rows per side, needF (F rows read beyond the owned ones), xF / xU (rows of the level's F /
+ * U halo that DO travel: xF on the critical path right after the finer level's `-1` launch, xU on a second stream,
+ * needed only when the cycle comes back up through the level).
+ *   ca_mode 0: exchange every halo (one group per level); 1 (default): recompute F halos while the extra rows stay
+ *   below ca_pct per cent of a slab (default 10); 2: recompute U halos too.  Negative = env MG_SLAB_CA / MG_SLAB_CA_PCT.
+ * level_out[l*6 ..] = {N, collapsed, halo, needF, xF, xU}; rank_out[(l*nranks + r)*8 ..] = {own, dext, ext, fwr} as
+ * [lo, hi) pairs.  Returns the number of levels, -1 when a halo would not fit the neighbouring slab. */
+int  mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int steps, int ca_mode, int ca_pct,
+                      int *level_out, int *rank_out);
 
 typedef struct mg_slab_plan mg_slab_plan;
 /* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:

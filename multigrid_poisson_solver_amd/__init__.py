@@ -83,7 +83,7 @@ ABI = {
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
-    "mg_slab_ghost_depths": (_i, [_i, _i, _i, _i, _i, C.POINTER(_i)]),
+    "mg_slab_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
@@ -551,13 +551,25 @@ def slab_partition(N_max, N_min, nranks, collapse_N):
     return [(sizes[l], bool(coll[l]), [tuple(int(v) for v in out[l, r]) for r in range(nranks)]) for l in range(nl)]
 
 
-def slab_ghost_depths(N_max, N_min, nranks, collapse_N, steps):
-    """mg_slab_ghost_depths: ghost rows per level that travel in an exchange (0 for collapsed levels)."""
-    out = (_i * 64)()
-    n = load_library().mg_slab_ghost_depths(N_max, N_min, nranks, collapse_N, steps, out)   # host-only: no GPU needed
+def slab_schedule(N_max, N_min, nranks, collapse_N, steps, ca_mode=-1, ca_pct=-1):
+    """mg_slab_schedule (host-only): per level a dict N, collapsed, halo, needF, xF, xU and, per rank, the row
+    ranges own / dext / ext / fwr as (lo, hi) tuples."""
+    lib_ = load_library()
+    nl = lib_.mg_slab_partition(N_max, N_min, nranks, collapse_N, None, None)
+    lev = np.zeros((nl, 6), dtype=np.int32)
+    rk = np.zeros((nl, nranks, 8), dtype=np.int32)
+    n = lib_.mg_slab_schedule(N_max, N_min, nranks, collapse_N, steps, ca_mode, ca_pct, lev.ctypes.data, rk.ctypes.data)
     if n < 0:
-        raise MGError("mg_slab_ghost_depths: the halo cannot hold this hierarchy")
-    return [int(out[i]) for i in range(n)]
+        lib_.mg_clear_error()
+        raise MGError("mg_slab_schedule: a halo does not fit the neighbouring slab (raise collapse_N)")
+    out = []
+    for l in range(nl):
+        d = dict(N=int(lev[l, 0]), collapsed=bool(lev[l, 1]), halo=int(lev[l, 2]), needF=int(lev[l, 3]), xF=int(lev[l, 4]),
+                 xU=int(lev[l, 5]))
+        for k, name in enumerate(("own", "dext", "ext", "fwr")):
+            d[name] = [(int(rk[l, r, 2 * k]), int(rk[l, r, 2 * k + 1])) for r in range(nranks)]
+        out.append(d)
+    return out
 
 
 def slab_ghost_rows():

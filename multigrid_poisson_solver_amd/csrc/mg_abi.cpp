@@ -120,10 +120,11 @@ static bool stream_is_capturing(hipStream_t s)
     return st != hipStreamCaptureStatusNone;
 }
 
-ProfScope::ProfScope(const char *name, int N, double algo_bytes)
+ProfScope::ProfScope(const char *name, int N, double algo_bytes, hipStream_t stream)
 {
     Context &c = ctx();
-    if (!c.profiling || N < c.profile_min_N || stream_is_capturing(c.stream)) return;
+    on = stream ? stream : c.stream;
+    if (!c.profiling || N < c.profile_min_N || stream_is_capturing(on)) return;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
         if (!c.event_pool.empty()) {
@@ -136,14 +137,14 @@ ProfScope::ProfScope(const char *name, int N, double algo_bytes)
     Context::ProfRec r{name, N, algo_bytes, e[0], e[1]};
     c.prof.push_back(r);
     slot = (int)c.prof.size() - 1;
-    (void)hipEventRecord(e[0], c.stream);
+    (void)hipEventRecord(e[0], on);
 }
 
 ProfScope::~ProfScope()
 {
     if (slot < 0) return;
     Context &c = ctx();
-    (void)hipEventRecord(c.prof[slot].e1, c.stream);
+    (void)hipEventRecord(c.prof[slot].e1, on);
 }
 
 double *norm_partials(size_t n)

@@ -33,6 +33,8 @@ namespace mg {
 namespace {
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_nranks = 1;
+hipStream_t g_stream = nullptr;   // comm_set_stream: where the next operations are enqueued (nullptr: the engine's stream)
+inline hipStream_t cur_stream() { return g_stream ? g_stream : ctx().stream; }
 
 // ---- RCCL entry points, resolved lazily -------------------------------------------------------
 struct Rccl {
@@ -118,8 +120,7 @@ std::vector<HostOp> g_ops;
 void host_flush()
 {
     if (g_ops.empty()) return;
-    Context &c = ctx();
-    (void)hipStreamSynchronize(c.stream);  // the rows being sent were written by kernels on this stream
+    (void)hipStreamSynchronize(cur_stream());  // the rows being sent were written by kernels this stream has waited for
     const size_t n = g_ops.size();
     std::vector<std::vector<unsigned char>> stage(n);
     std::vector<int> is_send(n), peer(n);
@@ -156,6 +157,7 @@ bool nccl_ok(ncclResult_t r, const char *what)
 }  // namespace
 
 bool comm_ready() { return g_comm != nullptr || g_host_on; }
+void comm_set_stream(hipStream_t s) { g_stream = s; }
 int comm_rank() { return g_rank; }
 int comm_size() { return g_nranks; }
 
@@ -186,7 +188,7 @@ void comm_send(const void *buf, size_t bytes, int peer)
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(g_rccl.Send(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.Send(buf, bytes, ncclChar, peer, g_comm, cur_stream()));
 }
 void comm_recv(void *buf, size_t bytes, int peer)
 {
@@ -196,13 +198,12 @@ void comm_recv(void *buf, size_t bytes, int peer)
         if (g_group_depth == 0) host_flush();
         return;
     }
-    MG_NCCL(g_rccl.Recv(buf, bytes, ncclChar, peer, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.Recv(buf, bytes, ncclChar, peer, g_comm, cur_stream()));
 }
 void comm_allgather(const double *send, double *recv, size_t count_per_rank)
 {
     if (g_host_on) {
-        Context &c = ctx();
-        (void)hipStreamSynchronize(c.stream);
+        (void)hipStreamSynchronize(cur_stream());
         std::vector<double> in(count_per_rank), out(count_per_rank * (size_t)g_nranks);
         if (!MG_HIP(hipMemcpy(in.data(), send, in.size() * sizeof(double), hipMemcpyDeviceToHost))) return;
         if (g_host.allgather(g_host.user, in.data(), out.data(), count_per_rank) != 0) {
@@ -212,7 +213,7 @@ void comm_allgather(const double *send, double *recv, size_t count_per_rank)
         (void)MG_HIP(hipMemcpy(recv, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
         return;
     }
-    MG_NCCL(g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, g_comm, ctx().stream));
+    MG_NCCL(g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, g_comm, cur_stream()));
 }
 
 }  // namespace mg

@@ -122,9 +122,10 @@ struct Context {
 
 // live kernel timing: RAII event pair around a launch (no-op unless profiling is on)
 struct ProfScope {
-    ProfScope(const char *name, int N, double algo_bytes);
+    ProfScope(const char *name, int N, double algo_bytes, hipStream_t stream = nullptr);  // nullptr: the engine's stream
     ~ProfScope();
     int slot = -1;
+    hipStream_t on = nullptr;
 };
 
 Context &ctx();
@@ -163,6 +164,7 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
 
 // RCCL transport (mg_comm.cpp)
 bool comm_ready();
+void comm_set_stream(hipStream_t s);   // stream of the following operations (nullptr: the engine's stream)
 int comm_rank();
 int comm_size();
 void comm_group_begin();

@@ -3,21 +3,32 @@
 // New work with no counterpart in the reference (single device).  The
 // fine levels of the hierarchy are cut into contiguous row slabs, one per rank; a slab is one
 // contiguous block of the row-major array and a ghost row is one contiguous message.  Each
-// slab carries GHOST rows of halo on either side.  Because the smoother is temporally
-// blocked, ONE exchange of ghost rows feeds a whole fused node (S sweeps + residual +
-// restriction, or prolongation + S sweeps): per level and V-cycle there is ONE exchange, on the
-// way down (the next level's F halo together with this level's U halo), and none on the way up:
-// a `1` node also updates the few halo rows of its level that the next finer level's
-// prolongation will read (at most 7 rows per side, the fixed point of e -> (e + S + 2)/2 + 1),
-// from inputs that are already there -- U and F halos from the descent, the coarse U rows it
-// computed redundantly itself one node earlier.  Redundant rows are bit-identical to the
-// neighbour's owned rows (same inputs, same arithmetic).
+// slab carries halo rows on either side (per level as many as the schedule below needs).
+//
+// Because the smoother is temporally blocked, one set of halo rows feeds a whole fused node (S sweeps +
+// residual + restriction, or prolongation + S sweeps), and because xGMI exchanges are LATENCY-bound
+// (a ghost message is a few hundred KiB; an RCCL group costs tens of microseconds whatever it carries)
+// the schedule is communication-avoiding:
+//   * way DOWN: a `-1` launch updates not only the rows its rank owns but as many rows beyond them as the
+//     NEXT level's launches will read of the restricted residual (halo of the next level's F): those rows
+//     are recomputed redundantly instead of exchanged.  The finest F comes from getSource, which every rank
+//     evaluates on its whole window, so the descent needs NO exchange while the extra rows stay below a
+//     share of the slab (MG_SLAB_CA_PCT, default 10 %: beyond that the next level's F halo is exchanged
+//     instead, which resets the growth);
+//   * way UP: a `1` node also updates the few halo rows of its level that the next finer level's
+//     prolongation will read (at most 7 rows per side, the fixed point of e -> (e + S + 2)/2 + 1), from
+//     inputs that are already there.  The halo of U that a `1` node reads is either part of what the
+//     descent computed redundantly or travels in ONE exchange issued right after the level's `-1` launch on
+//     a second stream: it is needed only when the cycle comes back up, so it overlaps with the whole
+//     coarser part of the cycle.
+// Redundant rows are bit-identical to the neighbour's owned rows (same inputs, same arithmetic).
 // Levels at or below collapse_N are collapsed: after the last
 // distributed restriction every rank hands its rows of that level's F to the others, and
 // EVERY rank -- rank 0 included -- runs that part of the cycle file on the whole coarse grid
 // with the single-GPU operators.  Replicating the collapsed levels instead of parking them on
 // rank 0 costs nothing (the other ranks would idle) and removes the broadcast of the coarse
-// correction from the critical path; all ranks hold bit-identical copies.
+// correction from the critical path; all ranks hold bit-identical copies.  That all-gather is the
+// one communication step on the critical path of a V-cycle.
 //
 // Ranks may all live in THIS process ("virtual ranks": exchanges are device-to-device
 // copies) -- that is how the decomposition is tested bit-for-bit on a one-GPU box -- or one
@@ -39,10 +50,31 @@
 namespace mg {
 namespace {
 
-// Halo rows per side.  S+2 would do for one fused node (mg_stream_impl.h Halo<>); 14 also covers the
-// rows a rank computes REDUNDANTLY on the way up (see ext below), so that the ascent needs no exchange
-// (S = 4 sweeps per node: up to 8 redundant rows + the S+2 rows a launch reads beyond them).
-constexpr int GHOST = 14;
+// A level stays distributed while every slab keeps at least 2 * MIN_HALF rows (S = 4 sweeps per node: up to
+// 8 redundant rows on the way up + the S+2 rows a launch reads beyond them = 14 per side); how many halo
+// rows a level's arrays really carry is decided by the schedule (LevelPlan::halo).
+constexpr int MIN_HALF = 14;
+
+struct Span {  // rows [lo, hi)
+    int lo = 0, hi = 0;
+};
+inline Span clip(Span s, int N) { return Span{std::max(0, s.lo), std::min(N, s.hi)}; }
+inline Span unite(Span a, Span b) { return Span{std::min(a.lo, b.lo), std::max(a.hi, b.hi)}; }
+inline Span grow(Span s, int h, int N) { return clip(Span{s.lo - h, s.hi + h}, N); }
+inline bool inside(Span a, Span b) { return a.lo >= b.lo && a.hi <= b.hi; }  // a within b
+inline int beyond(Span s, Span own) { return std::max(own.lo - s.lo, s.hi - own.hi); }
+
+// what one distributed level does on every rank (per GLOBAL rank)
+struct LevelPlan {
+    std::vector<Span> own;   // rows the rank owns
+    std::vector<Span> dext;  // rows its `-1` launch updates: own + what the next level's F halo needs (recomputed, not exchanged)
+    std::vector<Span> ext;   // rows its `1` launch updates: own + what the next finer level's prolongation reads
+    std::vector<Span> fwr;   // rows of THIS level's F that the finer level's `-1` launch of the rank writes
+    int halo = 0;            // halo rows per side the level's arrays carry
+    int needF = 0;           // rows of F beyond the owned rows that the level's launches read
+    int xF = 0;              // > 0: that many rows of this level's F are exchanged after the finer level's `-1` launch
+    int xU = 0;              // > 0: that many rows of this level's U are exchanged after its own `-1` launch
+};
 
 struct Partition {
     std::vector<int> lo, hi;  // rows [lo[r], hi[r]) owned by global rank r
@@ -95,7 +127,8 @@ struct Local {  // one local rank's arrays of one level
 
 struct Level {
     int N = 0;
-    int hier = 0;             // index into the plan's hierarchy (sizes / parts / ext / depth)
+    int hier = 0;             // index into the plan's hierarchy (sizes / parts / lp)
+    int halo = 0;             // halo rows per side of a distributed level's windows
     bool collapsed = false;   // whole grid replicated on every rank
     Partition part;           // distributed levels
     std::vector<Local> loc;   // per local rank (collapsed: full N x N arrays, distributed: windows)
@@ -138,22 +171,24 @@ struct mg_slab_plan {
     double *refine_raw = nullptr;  // [refinements-1][n_local] raw residual norms of the intermediate iterates
     double *refine_all = nullptr;  // real mode: all-gather target
     std::vector<double> refine_err;
-    // per hierarchy index and GLOBAL rank: the rows a `1` node updates = owned rows + the halo rows the
-    // next finer level's `1` node reads through the prolongation (distributed levels only)
-    std::vector<std::vector<std::pair<int, int>>> ext;
-    std::vector<int> depth;      // per hierarchy index: ghost rows that actually travel (<= GHOST, what the level reads)
+    std::vector<LevelPlan> lp;   // per hierarchy index: the schedule of the distributed levels (slab_schedule)
     bool poison = false;         // MG_SLAB_POISON: fresh level arrays are filled with NaN (tests)
+    // exchanges run on a second stream: one event pair per hierarchy index (launch done -> exchange may start,
+    // exchange done -> the consumer may start); pending[l]: level l's U halo is still on its way
+    hipStream_t comm = nullptr;
+    std::vector<hipEvent_t> ev_ready, ev_done;
+    std::vector<char> pending;
 };
 
 namespace {
 
-RowWindow window_of(const Partition &part, int r)
+RowWindow window_of(const Level &lv, int r)
 {
     RowWindow w;
-    w.own_lo = part.lo[(size_t)r];
-    w.own_hi = part.hi[(size_t)r];
-    w.base = w.own_lo - GHOST;
-    w.rows = (w.own_hi - w.own_lo) + 2 * GHOST;
+    w.own_lo = lv.part.lo[(size_t)r];
+    w.own_hi = lv.part.hi[(size_t)r];
+    w.base = w.own_lo - lv.halo;
+    w.rows = (w.own_hi - w.own_lo) + 2 * lv.halo;
     return w;
 }
 
@@ -177,7 +212,7 @@ void alloc_level(mg_slab_plan *p, Level &lv)
         return;
     }
     for (size_t i = 0; i < p->local.size(); ++i) {
-        const RowWindow w = window_of(lv.part, p->local[i]);
+        const RowWindow w = window_of(lv, p->local[i]);
         const size_t bytes = (size_t)w.rows * lv.N * p->elem;
         lv.loc[i].U = (double *)p->pool.get(bytes);
         lv.loc[i].F = (double *)p->pool.get(bytes);
@@ -199,79 +234,96 @@ void free_level(mg_slab_plan *p, Level &lv)
     lv.loc.clear();
 }
 
-// ghost rows of arrays of distributed levels: every rank sends its top GHOST owned rows up and
-// its bottom GHOST owned rows down, and receives the neighbours' into its halo.  All arrays of
+// ghost rows of arrays of distributed levels: every rank sends its top `depth` owned rows up and
+// its bottom `depth` owned rows down, and receives the neighbours' into its halo.  All arrays of
 // one call travel in ONE RCCL group (one launch, both neighbours, both directions).
 enum Which { ARR_U, ARR_F };
 struct GhostItem {
     Level *lv;
     Which which;
+    int depth;  // rows per side
     // other arrays with the level's window geometry (the fp64 iterate of the refinement): one per local rank
     const std::vector<double *> *raw = nullptr;
     size_t raw_elem = 0;
-    int depth = 0;  // rows per side; 0: the level's own depth (plan->depth)
 };
-void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group);
+void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group, hipStream_t s);
 
+// Exchanges run on the plan's second stream: it first waits for what the engine's stream has enqueued so far
+// (the launch that produced the rows), and whoever consumes the received rows waits for ev_done[slot] -- at
+// once for rows on the critical path (a next level's F halo, the collapse all-gather), not before the cycle
+// comes back up through the level for a U halo (exchange_join), which hides that exchange behind the whole
+// coarser part of the cycle.
 // `share`/`share_part`: the collapse all-gather of the next level's F rides in the same group
-void exchange_ghosts(mg_slab_plan *p, const std::vector<GhostItem> &items, Level *share = nullptr,
+void exchange_ghosts(mg_slab_plan *p, size_t slot, const std::vector<GhostItem> &items, Level *share = nullptr,
                      const Partition *share_part = nullptr)
 {
     Context &c = ctx();
     const int R = p->nranks;
     if (R == 1) return;
     if (items.empty() && !share) return;
-    // live timing like every kernel launch (bench.py --gpus N reports it per level): event pair around the group
-    size_t bytes = 0;
-    for (const GhostItem &it : items)
-        bytes += (size_t)2 * (it.depth > 0 ? it.depth : p->depth[(size_t)it.lv->hier]) * it.lv->N * (it.raw ? it.raw_elem : p->elem);
-    ProfScope ps(share ? "ghost_exchange+collapse_allgather" : "ghost_exchange", items.empty() ? share->N : items[0].lv->N, (double)bytes);
-    if (p->real) comm_group_begin();
-    for (const GhostItem &it : items) {
-        Level &lv = *it.lv;
-        const int N = lv.N;
-        const size_t elem = it.raw ? it.raw_elem : p->elem;
-        // only the rows the level's launches read travel (the finest level: S+2 of the 12 halo rows)
-        const int G = it.depth > 0 ? it.depth : p->depth[(size_t)lv.hier];
-        const size_t cnt = (size_t)G * N * elem;  // bytes
-        auto arr = [&](size_t i) { return it.raw ? (*it.raw)[i] : (it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F); };
-        auto rows_from = [&](double *a, const RowWindow &w, int y) {  // row y of an array with this item's element size
-            return (void *)((char *)a + (size_t)(y - w.base) * N * elem);
-        };
-        if (!p->real) {
-            for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
-                const RowWindow a = window_of(lv.part, r), b = window_of(lv.part, r + 1);
-                double *A = arr((size_t)r), *B = arr((size_t)r + 1);
-                // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
-                (void)hipMemcpyAsync(rows_from(B, b, b.own_lo - G), rows_from(A, a, a.own_hi - G), cnt,
-                                     hipMemcpyDeviceToDevice, c.stream);
-                (void)hipMemcpyAsync(rows_from(A, a, a.own_hi), rows_from(B, b, b.own_lo), cnt, hipMemcpyDeviceToDevice,
-                                     c.stream);
+    hipStream_t s = p->comm;
+    (void)hipEventRecord(p->ev_ready[slot], c.stream);
+    (void)hipStreamWaitEvent(s, p->ev_ready[slot], 0);
+    {
+        // live timing like every kernel launch (bench.py --gpus N reports it per level): event pair around the group
+        size_t bytes = 0;
+        for (const GhostItem &it : items) bytes += (size_t)2 * it.depth * it.lv->N * (it.raw ? it.raw_elem : p->elem);
+        ProfScope ps(share ? "ghost_exchange+collapse_allgather" : "ghost_exchange", items.empty() ? share->N : items[0].lv->N, (double)bytes, s);
+        comm_set_stream(s);
+        if (p->real) comm_group_begin();
+        for (const GhostItem &it : items) {
+            Level &lv = *it.lv;
+            const int N = lv.N;
+            const size_t elem = it.raw ? it.raw_elem : p->elem;
+            const int G = it.depth;
+            const size_t cnt = (size_t)G * N * elem;  // bytes
+            auto arr = [&](size_t i) { return it.raw ? (*it.raw)[i] : (it.which == ARR_U ? lv.loc[i].U : lv.loc[i].F); };
+            auto rows_from = [&](double *a, const RowWindow &w, int y) {  // row y of an array with this item's element size
+                return (void *)((char *)a + (size_t)(y - w.base) * N * elem);
+            };
+            if (!p->real) {
+                for (int r = 0; r + 1 < R; ++r) {  // pair (r, r+1), both local
+                    const RowWindow a = window_of(lv, r), b = window_of(lv, r + 1);
+                    double *A = arr((size_t)r), *B = arr((size_t)r + 1);
+                    // a's top owned rows -> b's lower halo; b's bottom owned rows -> a's upper halo
+                    (void)hipMemcpyAsync(rows_from(B, b, b.own_lo - G), rows_from(A, a, a.own_hi - G), cnt, hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(rows_from(A, a, a.own_hi), rows_from(B, b, b.own_lo), cnt, hipMemcpyDeviceToDevice, s);
+                }
+                continue;
             }
-            continue;
+            const int r = p->local[0];
+            const RowWindow w = window_of(lv, r);
+            double *A = arr(0);
+            if (r + 1 < R) {
+                comm_send(rows_from(A, w, w.own_hi - G), cnt, r + 1);
+                comm_recv(rows_from(A, w, w.own_hi), cnt, r + 1);
+            }
+            if (r > 0) {
+                comm_send(rows_from(A, w, w.own_lo), cnt, r - 1);
+                comm_recv(rows_from(A, w, w.own_lo - G), cnt, r - 1);
+            }
         }
-        const int r = p->local[0];
-        const RowWindow w = window_of(lv.part, r);
-        double *A = arr(0);
-        if (r + 1 < R) {
-            comm_send(rows_from(A, w, w.own_hi - G), cnt, r + 1);
-            comm_recv(rows_from(A, w, w.own_hi), cnt, r + 1);
-        }
-        if (r > 0) {
-            comm_send(rows_from(A, w, w.own_lo), cnt, r - 1);
-            comm_recv(rows_from(A, w, w.own_lo - G), cnt, r - 1);
-        }
+        if (share) share_rows(p, *share, *share_part, true, s);
+        if (p->real) comm_group_end();
+        comm_set_stream(nullptr);
     }
-    if (share) share_rows(p, *share, *share_part, true);
-    if (p->real) comm_group_end();
+    (void)hipEventRecord(p->ev_done[slot], s);
+    p->pending[slot] = 1;
+}
+
+// the engine's stream waits for the exchange of `slot` (no-op when none is outstanding)
+void exchange_join(mg_slab_plan *p, size_t slot)
+{
+    if (slot >= p->pending.size() || !p->pending[slot]) return;
+    (void)hipStreamWaitEvent(ctx().stream, p->ev_done[slot], 0);
+    p->pending[slot] = 0;
 }
 
 // collapse boundary: every rank wrote its rows [cpart.lo, cpart.hi) of the coarse F into its own
 // full M x M array; afterwards every rank holds all rows (an all-gather with per-rank row
 // counts, issued as one group of point-to-point transfers)
-void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group)
+void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_open_group, hipStream_t s)
 {
-    Context &c = ctx();
     const int M = coarse.N, R = p->nranks;
     if (R == 1) return;
     auto off = [&](int r) { return (size_t)cpart.lo[(size_t)r] * M * p->elem; };                            // bytes
@@ -281,7 +333,7 @@ void share_rows(mg_slab_plan *p, Level &coarse, const Partition &cpart, bool in_
             for (int dst = 0; dst < R; ++dst)
                 if (src != dst)
                     (void)hipMemcpyAsync((char *)coarse.loc[(size_t)dst].F + off(src), (char *)coarse.loc[(size_t)src].F + off(src),
-                                         cnt(src), hipMemcpyDeviceToDevice, c.stream);
+                                         cnt(src), hipMemcpyDeviceToDevice, s);
         return;
     }
     const int me = p->local[0];
@@ -337,7 +389,10 @@ void run(mg_slab_plan *p)
             nxt.N = M;
             nxt.hier = hier;
             nxt.collapsed = p->level_collapsed[(size_t)hier];
-            if (!nxt.collapsed) nxt.part = p->parts[(size_t)hier];
+            if (!nxt.collapsed) {
+                nxt.part = p->parts[(size_t)hier];
+                nxt.halo = p->lp[(size_t)hier].halo;
+            }
             alloc_level(p, nxt);
             {
                 bool ok = true;
@@ -394,16 +449,23 @@ void run(mg_slab_plan *p)
             } else {
                 const int rec = add_record(p, -1, cur.N, step, 0);
                 const Partition cpart = nxt.collapsed ? induced_partition(cur.part, cur.N, M) : nxt.part;
+                const LevelPlan &plan_cur = p->lp[(size_t)cur.hier];
                 for (size_t i = 0; i < p->local.size(); ++i) {
                     const int r = p->local[i];
                     SlabFusion sf;
-                    sf.fine_w = window_of(cur.part, r);
+                    sf.fine_w = window_of(cur, r);
+                    sf.fine_w.norm_lo = sf.fine_w.own_lo;  // the error counts owned rows only
+                    sf.fine_w.norm_hi = sf.fine_w.own_hi;
+                    // ... but the launch also updates the rows beyond them whose restricted residual the next
+                    // level's launches will read (recomputed here instead of exchanged)
+                    sf.fine_w.own_lo = plan_cur.dext[(size_t)r].lo;
+                    sf.fine_w.own_hi = plan_cur.dext[(size_t)r].hi;
                     sf.M = M;
                     sf.Fc = nxt.loc[i].F;
                     // a collapsed next level is a full array on every rank: this rank writes its rows
-                    sf.fc_w = nxt.collapsed ? RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]} : window_of(nxt.part, r);
+                    sf.fc_w = nxt.collapsed ? RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]} : window_of(nxt, r);
                     // U starts from zero on every descent (:252-257; a restart inside one file is
-                    // not supported in slab mode), so no U ghost exchange is needed before the launch
+                    // not supported in slab mode), so the launch reads no U at all
                     if (p->mixed)
                         slab_smooth_f32(cur.N, p->L, nullptr, (float *)cur.loc[i].U, (const float *)cur.loc[i].F, step,
                                         raw_slot(p, (size_t)rec, i), sf);
@@ -412,13 +474,16 @@ void run(mg_slab_plan *p)
                 }
                 p->levels.push_back(nxt);
                 Level &fine_lv = p->levels[p->levels.size() - 2], &next_lv = p->levels.back();
-                // ONE group: the next level's F halo (needed by its own descent) and this level's U
-                // halo (needed when the cycle comes back up through this level)
+                // ONE group on the second stream: this level's U halo (read when the cycle comes back up through
+                // this level: nobody waits for it before that), the next level's F halo where the schedule
+                // exchanges it instead of recomputing it, and, at the collapse boundary, the all-gather of the
+                // next level's F rows -- the latter two are on the critical path and are joined at once
                 std::vector<GhostItem> items;
-                items.push_back(GhostItem{&fine_lv, ARR_U});
-                if (!next_lv.collapsed) items.push_back(GhostItem{&next_lv, ARR_F});
-                // ... and, at the collapse boundary, the all-gather of the next level's F rows
-                exchange_ghosts(p, items, next_lv.collapsed ? &next_lv : nullptr, &cpart);
+                if (plan_cur.xU > 0) items.push_back(GhostItem{&fine_lv, ARR_U, plan_cur.xU});
+                const int xF = next_lv.collapsed ? 0 : p->lp[(size_t)next_lv.hier].xF;
+                if (xF > 0) items.push_back(GhostItem{&next_lv, ARR_F, xF});
+                exchange_ghosts(p, (size_t)fine_lv.hier, items, next_lv.collapsed ? &next_lv : nullptr, &cpart);
+                if (xF > 0 || next_lv.collapsed) exchange_join(p, (size_t)fine_lv.hier);
                 continue;
             }
             p->levels.push_back(nxt);
@@ -451,20 +516,22 @@ void run(mg_slab_plan *p)
                 }
             } else {
                 const int rec = add_record(p, 1, fine.N, step, 0);
-                // no exchange: the fine level's U and F halos came with its descent, and the halo rows of the
-                // coarse U that this launch reads were computed by this rank itself (ext, see mg_slab_load)
+                // the fine level's U halo (where it was exchanged and not recomputed) must have arrived by now;
+                // its F halo came with the descent, and the halo rows of the coarse U that this launch reads
+                // were computed by this rank itself (ext, see slab_schedule)
                 const size_t hier = (size_t)at;  // hierarchy index of the fine level
+                exchange_join(p, hier);
                 for (size_t i = 0; i < p->local.size(); ++i) {
                     const int r = p->local[i];
                     SlabFusion sf;
-                    sf.fine_w = window_of(fine.part, r);
+                    sf.fine_w = window_of(fine, r);
                     sf.fine_w.norm_lo = sf.fine_w.own_lo;  // the error counts owned rows only
                     sf.fine_w.norm_hi = sf.fine_w.own_hi;
-                    sf.fine_w.own_lo = p->ext[hier][(size_t)r].first;
-                    sf.fine_w.own_hi = p->ext[hier][(size_t)r].second;
+                    sf.fine_w.own_lo = p->lp[hier].ext[(size_t)r].lo;
+                    sf.fine_w.own_hi = p->lp[hier].ext[(size_t)r].hi;
                     sf.Nc = coarse.N;
                     sf.coarse = coarse.loc[i].U;
-                    sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse.part, r);
+                    sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse, r);
                     if (p->mixed)
                         slab_smooth_f32(fine.N, p->L, (const float *)fine.loc[i].U, (float *)fine.loc[i].D, (const float *)fine.loc[i].F,
                                         step, raw_slot(p, (size_t)rec, i), sf);
@@ -477,6 +544,7 @@ void run(mg_slab_plan *p)
             if (p->levels.size() == 1) came_back_up = true;
         }
     }
+    for (size_t l = 0; l < p->pending.size(); ++l) exchange_join(p, l);  // a file that never came back up
     flush_norms();
     c.defer_norms = false;
 }
@@ -487,19 +555,33 @@ extern "C" {
 
 int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 
-// host-only: (a) ext[l][r] = the rows a `1` node of level l updates on rank r: its owned rows plus what the
-// next finer level's `1` node will read of this level through the prolongation (rows orow[y], orow[y]+1 for
-// every fine row y that launch loads) -- computed redundantly instead of exchanged; (b) depth[l] = the ghost
-// rows of level l that actually travel: what its launches read beyond the owned rows.
-static bool slab_halo_plan(const std::vector<int> &sizes, const std::vector<Partition> &parts, const std::vector<bool> &collapsed,
-                           int nranks, int steps, std::vector<std::vector<std::pair<int, int>>> *ext_out,
-                           std::vector<int> *depth_out)
+// host-only: the schedule of the distributed levels (see the head of this file).
+//   ext[l][r]  rows a `1` node of level l updates on rank r: its owned rows plus what the next finer level's `1`
+//              node will read of this level through the prolongation (rows orow[y], orow[y]+1 for every fine row y
+//              that launch loads) -- computed redundantly instead of exchanged;
+//   dext[l][r] rows a `-1` node updates: its owned rows plus the fine rows whose restricted residual the next level's
+//              launches read beyond their owned rows (the next level's F halo), unless that costs more than max_pct
+//              per cent of a slab, in which case the next level's F halo is exchanged (xF) and the growth starts anew;
+//   xU[l]      rows of level l's U halo that have to travel because a `1` node reads them and the `-1` node did not
+//              update them.
+// ca_mode: 0 = exchange every halo (one group per level, the round-1 schedule), 1 = recompute F halos (default),
+// 2 = recompute the U halos as well (no ghost exchange at all, only the collapse all-gather).
+static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Partition> &parts, const std::vector<bool> &collapsed,
+                          int nranks, int steps, int ca_mode, int max_pct, std::vector<LevelPlan> *out)
 {
     const size_t nl = sizes.size();
+    size_t nd = 0;
+    while (nd < nl && !collapsed[nd]) ++nd;  // levels 0 .. nd-1 are distributed
     const int H = steps + 2;  // input rows a launch loads beyond the rows it updates (Halo<S> + 1 spare)
-    std::vector<std::vector<std::pair<int, int>>> ext(nl);
-    for (size_t l = 0; l < nl && !collapsed[l]; ++l) {
-        ext[l].resize((size_t)nranks);
+    const size_t R = (size_t)nranks;
+    std::vector<LevelPlan> lp(nl);
+    // owned rows and the rows of the way up, finest level first
+    for (size_t l = 0; l < nd; ++l) {
+        LevelPlan &P = lp[l];
+        P.own.resize(R);
+        P.ext.resize(R);
+        P.dext.resize(R);
+        P.fwr.resize(R);
         std::vector<int> owner;
         std::vector<double> wh, wl;
         if (l > 0) {
@@ -508,36 +590,109 @@ static bool slab_halo_plan(const std::vector<int> &sizes, const std::vector<Part
             wl.resize(owner.size());
             build_prolongation_table(sizes[l], sizes[l - 1], 0, owner.data(), wh.data(), wl.data());
         }
-        for (int r = 0; r < nranks; ++r) {
-            int lo = parts[l].lo[(size_t)r], hi = parts[l].hi[(size_t)r];
+        for (size_t r = 0; r < R; ++r) {
+            P.own[r] = Span{parts[l].lo[r], parts[l].hi[r]};
+            Span e = P.own[r];
             if (l > 0) {
                 const int Nf = sizes[l - 1], Nc = sizes[l];
-                const int first = std::max(0, ext[l - 1][(size_t)r].first - H);
-                const int last = std::min(Nf, ext[l - 1][(size_t)r].second + H) - 1;
-                lo = std::min(lo, std::max(0, owner[(size_t)first]));
-                hi = std::max(hi, std::min(Nc, owner[(size_t)last] + 2));
+                const Span f = grow(lp[l - 1].ext[r], H, Nf);
+                e.lo = std::min(e.lo, std::max(0, owner[(size_t)f.lo]));
+                e.hi = std::max(e.hi, std::min(Nc, owner[(size_t)f.hi - 1] + 2));
             }
-            const int own_lo = parts[l].lo[(size_t)r], own_hi = parts[l].hi[(size_t)r];
-            if (own_lo - lo + H > GHOST || hi - own_hi + H > GHOST) {
-                fail(MG_ERR_UNSUPPORTED, "row-slab mode: level %d needs %d redundant rows, more than the halo holds", sizes[l],
-                     std::max(own_lo - lo, hi - own_hi));
-                return false;
-            }
-            ext[l][(size_t)r] = std::make_pair(lo, hi);
+            P.ext[r] = e;
         }
     }
-    std::vector<int> depth(nl, GHOST);
-    for (size_t l = 0; l < nl && !collapsed[l]; ++l) {
-        int e = 0;
-        for (int r = 0; r < nranks; ++r) {
-            e = std::max(e, parts[l].lo[(size_t)r] - ext[l][(size_t)r].first);
-            e = std::max(e, ext[l][(size_t)r].second - parts[l].hi[(size_t)r]);
+    // rows of the way down, coarsest distributed level first
+    for (size_t l = nd; l-- > 0;) {
+        LevelPlan &P = lp[l];
+        const int N = sizes[l];
+        int rows_min = 1 << 30;
+        for (size_t r = 0; r < R; ++r) {
+            P.dext[r] = P.own[r];
+            if (ca_mode >= 2) P.dext[r] = unite(P.dext[r], grow(P.ext[r], H, N));  // U halo of the way up recomputed as well
+            rows_min = std::min(rows_min, P.own[r].hi - P.own[r].lo);
         }
-        depth[l] = std::min(GHOST, e + H);
+        if (l + 1 < nd) {
+            LevelPlan &C = lp[l + 1];
+            const int M = sizes[l + 1];
+            std::vector<int> lo((size_t)M);
+            std::vector<double> w((size_t)M);
+            build_restriction_table(N, M, lo.data(), w.data());
+            std::vector<Span> cand(R);
+            int growth = 0, needF = 0;
+            for (size_t r = 0; r < R; ++r) {
+                const Span need = grow(unite(C.dext[r], C.ext[r]), H, M);  // rows of the next level's F its launches read
+                needF = std::max(needF, beyond(need, C.own[r]));
+                cand[r] = P.dext[r];
+                const int ra = std::max(1, need.lo), rb = std::min(M - 2, need.hi - 1);
+                if (ra <= rb) cand[r] = unite(cand[r], Span{lo[(size_t)ra], lo[(size_t)rb] + 1});
+                growth = std::max(growth, beyond(cand[r], P.own[r]));
+            }
+            C.needF = needF;
+            if (ca_mode >= 1 && (long long)growth * 100 <= (long long)max_pct * rows_min) {
+                P.dext = cand;  // the next level's F halo is recomputed here
+                C.xF = 0;
+            } else {
+                C.xF = needF;   // ... or exchanged after this level's `-1` launch
+            }
+            // rows of the next level's F that each rank's `-1` launch writes
+            for (size_t r = 0; r < R; ++r) {
+                int first = -1, last = -2;
+                for (int rc = 1; rc <= M - 2; ++rc) {
+                    if (lo[(size_t)rc] >= P.dext[r].lo && lo[(size_t)rc] < P.dext[r].hi) {
+                        if (first < 0) first = rc;
+                        last = rc;
+                    }
+                }
+                Span f = first >= 0 ? Span{first, last + 1} : Span{C.own[r].lo, C.own[r].lo};
+                if (P.dext[r].lo == 0) f.lo = 0;      // the chunk that holds fine row 0 writes the coarse rim row 0,
+                if (P.dext[r].hi == N) f.hi = M;      // the one with fine row N-1 the rim row M-1
+                C.fwr[r] = f;
+            }
+        }
     }
-    if (ext_out) *ext_out = ext;
-    if (depth_out) *depth_out = depth;
+    if (nd > 0) {
+        LevelPlan &T = lp[0];
+        for (size_t r = 0; r < R; ++r) {
+            T.needF = std::max(T.needF, beyond(grow(unite(T.dext[r], T.ext[r]), H, sizes[0]), T.own[r]));
+            T.fwr[r] = T.own[r];
+        }
+    }
+    // U halos that have to travel, halo rows per level, and the check that a halo stays inside the neighbour's rows
+    for (size_t l = 0; l < nd; ++l) {
+        LevelPlan &P = lp[l];
+        const int N = sizes[l];
+        int rows_min = 1 << 30, halo = std::max(P.needF, P.xF);
+        for (size_t r = 0; r < R; ++r) {
+            rows_min = std::min(rows_min, P.own[r].hi - P.own[r].lo);
+            const Span needU = grow(P.ext[r], H, N);
+            if (!inside(needU, P.dext[r])) P.xU = std::max(P.xU, beyond(needU, P.own[r]));
+            halo = std::max(halo, beyond(unite(P.dext[r], P.ext[r]), P.own[r]));
+            halo = std::max(halo, beyond(P.fwr[r], P.own[r]));
+        }
+        halo = std::max(halo, P.xU);
+        P.halo = halo;
+        if (R > 1 && halo > rows_min) {
+            fail(MG_ERR_UNSUPPORTED, "row-slab mode: level %d needs %d halo rows but its smallest slab has %d rows (raise collapse_N)",
+                 N, halo, rows_min);
+            return false;
+        }
+    }
+    *out = lp;
     return true;
+}
+
+static int slab_ca_mode()
+{
+    const char *e = getenv("MG_SLAB_CA");
+    const int m = e ? atoi(e) : 1;
+    return m < 0 ? 0 : (m > 2 ? 2 : m);
+}
+static int slab_ca_pct()
+{
+    const char *e = getenv("MG_SLAB_CA_PCT");
+    const int v = e ? atoi(e) : 10;
+    return v < 0 ? 0 : v;
 }
 
 // host-only: the row ranges each rank owns on every level of the hierarchy a cycle file
@@ -554,7 +709,7 @@ int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out
         const int N = sizes[l];
         if (l > 0 && !collapsed) {
             Partition nx = induced_partition(cur, sizes[l - 1], N);
-            if (N <= collapse_N || N % 2 != 0 || min_rows(nx) < 2 * GHOST) collapsed = true;
+            if (N <= collapse_N || N % 2 != 0 || min_rows(nx) < 2 * MIN_HALF) collapsed = true;
             else cur = nx;
         }
         if (collapsed_out) collapsed_out[l] = collapsed ? 1 : 0;
@@ -568,11 +723,14 @@ int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out
     return (int)sizes.size();
 }
 
-int mg_slab_ghost_rows(void) { return GHOST; }
+int mg_slab_ghost_rows(void) { return MIN_HALF; }
 
-// host-only: how many ghost rows of each level actually travel (distributed levels; 0 for collapsed ones) for
-// `steps` sweeps per node; returns the number of levels or -1 when the halo cannot hold the hierarchy
-int mg_slab_ghost_depths(int N_max, int N_min, int nranks, int collapse_N, int steps, int *out)
+// host-only: the schedule mg_slab_load derives for a hierarchy (`steps` sweeps per node; ca_mode / ca_pct < 0: the
+// defaults resp. env MG_SLAB_CA / MG_SLAB_CA_PCT).  level_out[l*6 + ..] = {N, collapsed, halo, needF, xF, xU};
+// rank_out[(l*nranks + r)*8 + ..] = {own.lo, own.hi, dext.lo, dext.hi, ext.lo, ext.hi, fwr.lo, fwr.hi} (zeros for
+// collapsed levels).  Returns the number of levels, -1 when a halo would not fit its neighbour's slab.
+int mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int steps, int ca_mode, int ca_pct, int *level_out,
+                     int *rank_out)
 {
     std::vector<int> sizes;
     for (int n = N_max; n >= N_min && n > 0; n /= 2) sizes.push_back(n);
@@ -588,9 +746,32 @@ int mg_slab_ghost_depths(int N_max, int N_min, int nranks, int collapse_N, int s
             parts[l].hi.push_back(ranges[(l * (size_t)nranks + r) * 2 + 1]);
         }
     }
-    std::vector<int> depth;
-    if (!slab_halo_plan(sizes, parts, collapsed, nranks, steps, nullptr, &depth)) return -1;
-    for (size_t l = 0; l < nl; ++l) out[l] = collapsed[l] ? 0 : depth[l];
+    std::vector<LevelPlan> lp;
+    if (!slab_schedule(sizes, parts, collapsed, nranks, steps, ca_mode < 0 ? slab_ca_mode() : ca_mode,
+                       ca_pct < 0 ? slab_ca_pct() : ca_pct, &lp))
+        return -1;
+    for (size_t l = 0; l < nl; ++l) {
+        if (level_out) {
+            int *o = level_out + l * 6;
+            o[0] = sizes[l];
+            o[1] = collapsed[l] ? 1 : 0;
+            o[2] = lp[l].halo;
+            o[3] = lp[l].needF;
+            o[4] = lp[l].xF;
+            o[5] = lp[l].xU;
+        }
+        for (int r = 0; r < nranks && rank_out; ++r) {
+            int *o = rank_out + (l * (size_t)nranks + r) * 8;
+            for (int k = 0; k < 8; ++k) o[k] = 0;
+            if (collapsed[l]) continue;
+            const LevelPlan &P = lp[l];
+            const Span v[4] = {P.own[(size_t)r], P.dext[(size_t)r], P.ext[(size_t)r], P.fwr[(size_t)r]};
+            for (int k = 0; k < 4; ++k) {
+                o[2 * k] = v[k].lo;
+                o[2 * k + 1] = v[k].hi;
+            }
+        }
+    }
     return (int)nl;
 }
 
@@ -659,16 +840,28 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
             p->parts[l].hi.push_back(ranges[(l * (size_t)nranks + r) * 2 + 1]);
         }
     }
-    if (p->level_collapsed[0] || min_rows(p->parts[0]) < 2 * GHOST) {
+    if (p->level_collapsed[0] || min_rows(p->parts[0]) < 2 * MIN_HALF) {
         fail(MG_ERR_UNSUPPORTED, "row-slab mode: N_max=%d is too small for %d ranks", p->N_max, nranks);
         delete p;
         return nullptr;
     }
-    if (!slab_halo_plan(p->sizes, p->parts, p->level_collapsed, nranks, p->con_step, &p->ext, &p->depth)) {
+    if (!slab_schedule(p->sizes, p->parts, p->level_collapsed, nranks, p->con_step, slab_ca_mode(), slab_ca_pct(), &p->lp)) {
         delete p;
         return nullptr;
     }
     p->poison = getenv("MG_SLAB_POISON") != nullptr;
+    // second stream + event pairs for the exchanges (one pair per hierarchy index)
+    if (!MG_HIP(hipStreamCreateWithFlags(&p->comm, hipStreamNonBlocking))) {
+        delete p;
+        return nullptr;
+    }
+    p->ev_ready.resize(nl);
+    p->ev_done.resize(nl);
+    p->pending.assign(nl, 0);
+    for (size_t l = 0; l < nl; ++l) {
+        (void)hipEventCreateWithFlags(&p->ev_ready[l], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&p->ev_done[l], hipEventDisableTiming);
+    }
     size_t smoothing_nodes = 0;
     for (double t : p->tokens)
         if (t == -1.0 || t == 1.0 || t == 0.0) ++smoothing_nodes;
@@ -680,9 +873,10 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
     Level top;
     top.N = p->N_max;
     top.part = p->parts[0];
+    top.halo = p->lp[0].halo;
     alloc_level(p, top);
     for (size_t i = 0; i < p->local.size(); ++i) {
-        const RowWindow w = window_of(top.part, p->local[i]);
+        const RowWindow w = window_of(top, p->local[i]);
         const int lo = std::max(0, w.base), hi = std::min(top.N, w.base + w.rows);
         if (!p->mixed) {
             fill_source_rows(top.N, p->L, p->min_x, p->min_y, lo, hi, row_ptr(top.loc[i].F, w, top.N, lo));
@@ -729,9 +923,12 @@ int mg_slab_enqueue(mg_slab_plan *p)
             // mixed-precision refinement (mg_cycle_set_refinement on slabs): the fp32 source of this cycle is
             // the fp64 residual of the fp64 iterate (one halo row of it comes from the neighbours), rounded;
             // its own halo rows are exchanged like any F.  A new window first restores the rounded source.
-            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_U, &p->U64, sizeof(double), 1}});  // the 5-point star: one row
+            if (it > 0) {  // the 5-point star: one row
+                exchange_ghosts(p, 0, {GhostItem{&top, ARR_U, 1, &p->U64, sizeof(double)}});
+                exchange_join(p, 0);
+            }
             for (size_t i = 0; i < p->local.size(); ++i) {
-                const RowWindow w = window_of(top.part, p->local[i]);
+                const RowWindow w = window_of(top, p->local[i]);
                 if (it > 0) {
                     const double dx = p->L / (double)(top.N - 1);
                     k::refine_residual_rows(c.stream, top.N, 1.0 / (dx * dx), p->U64[i], p->F64[i], (float *)top.loc[i].F, w,
@@ -742,7 +939,10 @@ int mg_slab_enqueue(mg_slab_plan *p)
                                       (size_t)(hi - lo) * top.N);
                 }
             }
-            if (it > 0) exchange_ghosts(p, {GhostItem{&top, ARR_F}});
+            if (it > 0 && p->lp[0].needF > 0) {  // every halo row of the source the level's launches read
+                exchange_ghosts(p, 0, {GhostItem{&top, ARR_F, p->lp[0].needF}});
+                exchange_join(p, 0);
+            }
             p->F32_stale = it > 0;
         }
         run(p);
@@ -750,7 +950,7 @@ int mg_slab_enqueue(mg_slab_plan *p)
             // fp64 correction on the owned rows: U64 = (double)e on the first cycle, U64 += (double)e afterwards
             Level &top = p->levels[0];  // (run() grows the level vector: the reference above is gone)
             for (size_t i = 0; i < p->local.size(); ++i) {
-                const RowWindow w = window_of(top.part, p->local[i]);
+                const RowWindow w = window_of(top, p->local[i]);
                 const size_t n = (size_t)(w.own_hi - w.own_lo) * top.N;
                 double *u64 = row_ptr(p->U64[i], w, top.N, w.own_lo);
                 const float *e = (const float *)row_at(p, top.loc[i].U, w, top.N, w.own_lo);
@@ -793,7 +993,7 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
     Level &top = p->levels[0];
     const size_t nloc = p->local.size(), nrec = p->records.size();
     for (size_t i = 0; i < nloc && p->want_error; ++i) {
-        const RowWindow w = window_of(top.part, p->local[i]);
+        const RowWindow w = window_of(top, p->local[i]);
         const double *U = top.loc[i].U;
         if (p->mixed) {  // widen the whole window (exact) unless the refinement kept U64 up to date
             if (!p->U64_current) k::convert_to_f64(c.stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
@@ -803,7 +1003,7 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out)
     }
     std::vector<double> raw((p->max_rec + 1) * (size_t)p->nranks, 0.0);  // [slot][global rank]
     if (p->real) {
-        comm_allgather(p->raw_dev, p->all_dev, p->max_rec + 1);  // nloc == 1: [slot] per rank
+        comm_allgather(p->raw_dev, p->all_dev, p->max_rec + 1);  // nloc == 1: [slot] per rank (engine's stream: everything is joined)
         std::vector<double> tmp((p->max_rec + 1) * (size_t)p->nranks);
         mg_download(tmp.data(), p->all_dev, tmp.size());
         for (int r = 0; r < p->nranks; ++r)
@@ -866,7 +1066,7 @@ int mg_slab_gather_U(mg_slab_plan *p, double *host_full)
     if (!require_ready("mg_slab_gather_U") || !p) return 1;
     Level &top = p->levels[0];
     for (size_t i = 0; i < p->local.size(); ++i) {
-        const RowWindow w = window_of(top.part, p->local[i]);
+        const RowWindow w = window_of(top, p->local[i]);
         double *U = top.loc[i].U;
         if (p->mixed) {
             if (!p->U64_current) k::convert_to_f64(ctx().stream, p->U64[i], (const float *)top.loc[i].U, (size_t)w.rows * top.N);
@@ -923,6 +1123,12 @@ void mg_slab_destroy(mg_slab_plan *p)
     if (p->refine_all) p->pool.put(p->refine_all);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->comm) {
+        (void)hipStreamSynchronize(p->comm);
+        (void)hipStreamDestroy(p->comm);
+    }
+    for (hipEvent_t e : p->ev_ready) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->ev_done) (void)hipEventDestroy(e);
     p->pool.trim();
     delete p;
 }

@@ -1,10 +1,11 @@
 """World-size-N gloo worker (CPU): emulates the row-slab V-cycle of mg_slab.cpp with the CPU
-oracle as the local operator.  Every rank holds full-size arrays that are NaN outside its
-window (owned rows + GHOST halo rows), applies the oracle's whole-grid operators, exchanges
-exactly the ghost rows the engine exchanges (on the way down only; nothing on the way up) (over torch.distributed/gloo) and finally the
-assembled finest U must equal the oracle's single-domain result bit for bit with no NaN in
-any owned row -- which proves the partition (mg_slab_partition, the product's host code), the
-halo depth and the exchange schedule.  TEST INFRASTRUCTURE (uses oracle/).
+oracle as the local operator.  Every rank holds full-size arrays that are NaN wherever the engine's
+launches would not have written (a launch leaves exactly the rows the schedule says it updates),
+applies the oracle's whole-grid operators, exchanges exactly the ghost rows the schedule lets travel
+(over torch.distributed/gloo) and finally the assembled finest U must equal the oracle's
+single-domain result bit for bit with no NaN in any row a launch is supposed to produce -- which
+proves the partition and the communication-avoiding schedule (mg_slab_partition / mg_slab_schedule,
+the product's host code): which rows are recomputed, which travel, how deep the halos are.  TEST INFRASTRUCTURE (uses oracle/).
 
 torch is imported before the engine library on purpose (one HIP runtime per process).
 """
@@ -51,35 +52,53 @@ def window_array(full, lo, hi, G):
     return out
 
 
+def keep_rows(a, span):
+    """what a launch that updates rows [lo, hi) leaves behind: those rows, NaN everywhere else"""
+    out = np.full_like(a, np.nan)
+    out[span[0]:span[1]] = a[span[0]:span[1]]
+    return out
+
+
 def main():
     N, collapse, step, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    ca_mode, ca_pct = int(sys.argv[5]), int(sys.argv[6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     orc = _oracle.Oracle()
-    G = mg.slab_ghost_rows()                                  # halo rows a slab carries
-    depth = mg.slab_ghost_depths(N, 8, world, collapse, step)  # ... and how many of them travel, per level
-    levels = mg.slab_partition(N, 8, world, collapse)
-    sizes = [l[0] for l in levels]
+    # the product's own host code: partition + communication-avoiding schedule (mg_slab.cpp:slab_schedule)
+    sched = mg.slab_schedule(N, 8, world, collapse, step, ca_mode, ca_pct)
+    sizes = [d["N"] for d in sched]
     L = 1.0
-    first_collapsed = next(i for i, l in enumerate(levels) if l[1])
+    first_collapsed = next(i for i, d in enumerate(sched) if d["collapsed"])
 
-    U = [None] * len(levels)
-    F = [None] * len(levels)
-    own = [l[2][rank] for l in levels]
-    F[0] = window_array(orc.getSource(N), own[0][0], own[0][1], G)
+    U = [None] * len(sched)
+    F = [None] * len(sched)
+    own = [d["own"][rank] if not d["collapsed"] else None for d in sched]
+    # getSource is evaluated by every rank on its whole window (owned rows + halo): no exchange of the finest F
+    F[0] = window_array(orc.getSource(N), own[0][0], own[0][1], sched[0]["halo"])
+    exchanges = 0
 
     # ---- down through the distributed levels
     for l in range(first_collapsed):
         n, M = sizes[l], sizes[l + 1]
         lo, hi = own[l]
-        start = np.full((n, n), np.nan)
-        start[max(0, lo - G):min(n, hi + G)] = 0.0           # memset(U, 0), window only
-        U[l], _ = orc.doSmoothing(n, L, start, F[l], step)
-        assert not np.isnan(U[l][lo:hi]).any(), f"rank {rank}: NaN in owned U rows of level {n}"
-        Fc = orc.doRestriction(n, -orc.getResidual(n, L, U[l], F[l]), M)
+        dext = sched[l]["dext"][rank]
+        # memset(U, 0) is folded into the launch: the zero start needs no U halo at all
+        Ul, _ = orc.doSmoothing(n, L, np.zeros((n, n)), F[l], step)
+        assert not np.isnan(Ul[dext[0]:dext[1]]).any(), f"rank {rank}: NaN in the rows the -1 launch of level {n} updates"
+        U[l] = keep_rows(Ul, dext)   # the launch writes exactly these rows of U ...
+        Fc = orc.doRestriction(n, -orc.getResidual(n, L, Ul, F[l]), M)
         table_lo, _w = mg.restriction_table(n, M)
         if l + 1 < first_collapsed:
             clo, chi = own[l + 1]
+            fwr = sched[l + 1]["fwr"][rank]
+            # ... and the coarse F rows whose lower-left sample lies in them
+            rows = [rc for rc in range(1, M - 1) if dext[0] <= table_lo[rc] < dext[1]]
+            want = (0 if dext[0] == 0 else rows[0], M if dext[1] == n else rows[-1] + 1)
+            assert tuple(fwr) == want, f"rank {rank}: fwr of level {M}: {fwr} vs {want}"
+            assert fwr[0] >= clo - sched[l + 1]["halo"] and fwr[1] <= chi + sched[l + 1]["halo"], "written rows leave the window"
+            assert not np.isnan(Fc[fwr[0]:fwr[1]]).any(), f"rank {rank}: NaN in the coarse F rows written at level {M}"
+            F[l + 1] = keep_rows(Fc, fwr)
         else:  # collapse boundary: ownership induced by this level's partition
             rows = [rc for rc in range(1, M - 1) if lo <= table_lo[rc] < hi]
             clo, chi = (rows[0], rows[-1] + 1) if rows else (1, 1)
@@ -87,17 +106,16 @@ def main():
                 clo = 0
             if rank == world - 1:
                 chi = M
-        assert not np.isnan(Fc[clo:chi]).any(), f"rank {rank}: NaN in owned coarse F rows {M}"
-        # the engine exchanges this level's U halo right here, in the same group as the next
-        # level's F halo: it is needed when the cycle comes back up through this level
-        Ul = np.full((n, n), np.nan)
-        Ul[lo:hi] = U[l][lo:hi]
-        exchange(Ul, lo, hi, depth[l], rank, world)
-        U[l] = Ul
+            assert not np.isnan(Fc[clo:chi]).any(), f"rank {rank}: NaN in owned coarse F rows {M}"
+        # ONE group after the launch: this level's U halo where the schedule lets it travel (needed only when the
+        # cycle comes back up), the next level's F halo where it is exchanged instead of recomputed, the all-gather
+        if sched[l]["xU"] > 0:
+            exchange(U[l], lo, hi, sched[l]["xU"], rank, world)
+            exchanges += 1
         if l + 1 < first_collapsed:
-            F[l + 1] = np.full((M, M), np.nan)
-            F[l + 1][clo:chi] = Fc[clo:chi]
-            exchange(F[l + 1], clo, chi, depth[l + 1], rank, world)
+            if sched[l + 1]["xF"] > 0:
+                exchange(F[l + 1], clo, chi, sched[l + 1]["xF"], rank, world)
+                exchanges += 1
         else:
             parts = [None] * world
             dist.all_gather_object(parts, (clo, chi, Fc[clo:chi].copy()))
@@ -129,14 +147,15 @@ def main():
     for l in range(first_collapsed - 1, -1, -1):
         n, M = sizes[l], sizes[l + 1]
         lo, hi = own[l]
-        # NO exchange on the way up: the coarse halo rows this level reads through the prolongation are
-        # the ones this rank computed redundantly itself (whole-grid operators on NaN-poisoned windows
-        # compute every row whose inputs are there); GHOST is sized so that this reaches far enough
+        ext = sched[l]["ext"][rank]
+        # NO exchange on the way up: the coarse halo rows this level reads through the prolongation are the ones
+        # this rank computed redundantly itself one node earlier (ext of the coarser level), and this level's own U
+        # and F halos are there since the descent (recomputed, or exchanged right after the level's -1 launch)
         Uc = U[l + 1]
-        Uf = U[l]  # owned rows + the halo exchanged right after this level's descent
-        Uf = orc.doGridAddition(n, Uf, orc.doProlongation(M, Uc, n, fill=np.nan))
-        U[l], _ = orc.doSmoothing(n, L, Uf, F[l], step)
-        assert not np.isnan(U[l][lo:hi]).any(), f"rank {rank}: NaN in owned rows after the way up, level {n}"
+        Uf = orc.doGridAddition(n, U[l], orc.doProlongation(M, Uc, n, fill=np.nan))
+        Ul, _ = orc.doSmoothing(n, L, Uf, F[l], step)
+        assert not np.isnan(Ul[ext[0]:ext[1]]).any(), f"rank {rank}: NaN in the rows the 1 launch of level {n} updates"
+        U[l] = keep_rows(Ul, ext)
 
     parts = [None] * world
     dist.all_gather_object(parts, (own[0][0], own[0][1], U[0][own[0][0]:own[0][1]].copy()))
@@ -147,7 +166,7 @@ def main():
         want = orc.run_cycle_file(path)
         assert want["status"] == 0
         same = np.array_equal((got + 0.0).view(np.uint64), (want["U"] + 0.0).view(np.uint64))
-        print("SLAB_EMULATION", "OK" if same else "MISMATCH", world, N, collapse, flush=True)
+        print("SLAB_EMULATION", "OK" if same else "MISMATCH", world, N, collapse, f"mode {ca_mode} exchanges {exchanges}", flush=True)
         if not same:
             sys.exit(3)
     dist.barrier()

@@ -21,18 +21,23 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("world,N,collapse", [(2, 256, 32), (2, 128, 64), (3, 256, 64)])
-def test_row_slab_schedule_on_gloo(tmp_path, world, N, collapse):
+@pytest.mark.parametrize("world,N,collapse,ca_mode,ca_pct", [(2, 256, 32, 1, 10), (2, 128, 64, 0, 10), (3, 256, 64, 1, 100),
+                                                             (2, 256, 32, 2, 100), (2, 512, 32, 1, 100)])
+def test_row_slab_schedule_on_gloo(tmp_path, world, N, collapse, ca_mode, ca_pct):
+    """ca_mode 0: every halo exchanged (one group per level); 1: F halos recomputed while the extra rows stay below
+    ca_pct per cent of a slab (100: always); 2: U halos recomputed as well (no ghost exchange, only the all-gather)."""
     import multigrid_poisson_solver_amd as mg
     path = str(tmp_path / "V.txt")
     mg.write_vcycle_file(path, N, 8, 3, 1e-7)
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(HERE, "_slab_worker.py"), str(N), str(collapse), "3", path]
+           os.path.join(HERE, "_slab_worker.py"), str(N), str(collapse), "3", path, str(ca_mode), str(ca_pct)]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert f"SLAB_EMULATION OK {world} {N} {collapse}" in out.stdout
+    assert f"SLAB_EMULATION OK {world} {N} {collapse} mode {ca_mode}" in out.stdout
+    if ca_mode == 2:
+        assert "exchanges 0" in out.stdout
 
 
 def test_partition_properties():
@@ -42,6 +47,15 @@ def test_partition_properties():
     import multigrid_poisson_solver_amd as mg
     G = mg.slab_ghost_rows()
     assert G >= 6
+    # the bench configurations: the halos of the schedule fit, nothing but the last level's U halo travels
+    for N, R in [(16384, 8), (23040, 8), (11520, 2), (16384, 4), (16384, 2)]:
+        sched = [d for d in mg.slab_schedule(N, 8, R, 1024, 3) if not d["collapsed"]]
+        assert all(d["xF"] == 0 for d in sched) and [d["xU"] > 0 for d in sched] == [False] * (len(sched) - 1) + [True]
+        for d in sched:
+            rows = min(hi - lo for lo, hi in d["own"])
+            assert d["halo"] <= rows // 8, (N, R, d["N"], d["halo"], rows)
+            for r in range(R):
+                assert d["dext"][r][0] <= d["own"][r][0] and d["dext"][r][1] >= d["own"][r][1]
     for N, R, collapse in [(8192, 8, 1024), (23040, 8, 1024), (11520, 2, 1024), (23168, 8, 1024), (1024, 3, 128), (16384, 4, 512)]:
         levels = mg.slab_partition(N, 8, R, collapse)
         seen_collapsed = False
