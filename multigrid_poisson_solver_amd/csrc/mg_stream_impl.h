@@ -165,16 +165,22 @@ struct Row {
 // that is stored (a rim point keeps its value and never looks at its neighbours), and a load
 // that is always issued lets the compiler count the loads in flight: with predicated loads it
 // has to assume none was issued and waits for vmcnt(0) at every use.
+// Addresses are a wave-uniform row pointer (SGPR pair, advanced by one row per step) plus a 32-bit
+// per-lane element offset: the global_load/store then takes its `saddr + voffset` form and the row
+// walk costs two scalar additions instead of 64-bit vector arithmetic per lane.
+// (the lane offset is in BYTES: `uniform pointer + zero-extended 32-bit value` is the shape the instruction selector
+// needs; an element index would have to be scaled in 64 bits first)
 template <int COLS>
-__device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ base)
+__device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ row, unsigned col_bytes)
 {
     Row<COLS> r;
+    const char *a = reinterpret_cast<const char *>(row) + col_bytes;
     if constexpr (COLS == 2) {
-        const real2_t t = *reinterpret_cast<const real2_t *>(base);
+        const real2_t t = *reinterpret_cast<const real2_t *>(a);
         r.v[0] = t.x;
         r.v[1] = t.y;
     } else {
-        r.v[0] = *base;
+        r.v[0] = *reinterpret_cast<const real_t *>(a);
     }
     return r;
 }
@@ -183,16 +189,17 @@ __device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ base)
 // non-temporal store keeps it from displacing the halo rows and coarse rows the neighbouring
 // tiles re-read (wave-uniform flag, set for N >= 2048)
 template <int COLS>
-__device__ __forceinline__ void store_row(real_t *__restrict__ base, const Row<COLS> &r, bool nt)
+__device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col_bytes, const Row<COLS> &r, bool nt)
 {
+    char *a = reinterpret_cast<char *>(row) + col_bytes;
     if constexpr (COLS == 2) {
         real2_t t;
         t.x = r.v[0];
         t.y = r.v[1];
-        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real2_t *>(base));
-        else *reinterpret_cast<real2_t *>(base) = t;
+        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real2_t *>(a));
+        else *reinterpret_cast<real2_t *>(a) = t;
     } else {
-        *base = r.v[0];
+        *reinterpret_cast<real_t *>(a) = r.v[0];
     }
 }
 
@@ -204,22 +211,58 @@ struct Halo {
     static constexpr int value = (S + (RESTRICT ? 2 : 1) + 1) & ~1;
 };
 
+// `zero ? 0 : v` for a lane constant v whose low 32 bits are zero (0.25, +-1.0, 0.0) and a wave-uniform
+// condition: ONE select on the high dword instead of two
+__device__ __forceinline__ double uniform_or_zero(bool zero, double v)
+{
+    const int hi = zero ? 0 : __double2hiint(v);
+    return __hiloint2double(hi, 0);
+}
+__device__ __forceinline__ float uniform_or_zero(bool zero, float v) { return zero ? 0.0f : v; }
+__device__ __forceinline__ double fused_mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fused_mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // three consecutive coarse values of one coarse row, starting at this lane's base column
 struct Coarse3 {
     real_t v[3];
 };
+// unconditional like load_row: rows fetched ahead of need may lie outside the local window (clamped)
+// and columns past the grid are clamped (never consumed); col[] are the lane's three clamped columns
 __device__ __forceinline__ Coarse3 load_coarse(const real_t *__restrict__ coarse, int Nc, int base, int rows, int row,
-                                               int col)
+                                               const unsigned (&col)[3])
 {
-    // unconditional like load_row: rows fetched ahead of need may lie outside the local window
-    // and columns past the grid are clamped (never consumed)
     Coarse3 c;
     int r = row - base;
     r = r < 0 ? 0 : (r < rows - 1 ? r : rows - 1);
-    const real_t *b = coarse + (size_t)r * Nc;
-    c.v[0] = b[col];
-    c.v[1] = b[col + 1 < Nc ? col + 1 : Nc - 1];
-    c.v[2] = b[col + 2 < Nc ? col + 2 : Nc - 1];
+    const char *b = reinterpret_cast<const char *>(coarse + (size_t)r * Nc);
+    c.v[0] = *reinterpret_cast<const real_t *>(b + col[0]);   // col[] in bytes
+    c.v[1] = *reinterpret_cast<const real_t *>(b + col[1]);
+    c.v[2] = *reinterpret_cast<const real_t *>(b + col[2]);
+    return c;
+}
+
+// value of lane `lane` (wave-uniform) of a register, as a wave-uniform value
+__device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// v with every bit cleared where mask == 0 (mask is 0 or -1): +0.0 or v, also for a NaN
+__device__ __forceinline__ double bits_and(double v, int mask) { return __hiloint2double(__double2hiint(v) & mask, __double2loint(v) & mask); }
+__device__ __forceinline__ float bits_and(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
+// the same for a constant whose low 32 bits are zero (0.25, +-1.0): one AND on the high dword
+__device__ __forceinline__ double hi_bits_and(double v, int mask) { return __hiloint2double(__double2hiint(v) & mask, 0); }
+__device__ __forceinline__ float hi_bits_and(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
+
+// the same with the local (already clamped) row index of the coarse array
+__device__ __forceinline__ Coarse3 load_coarse_local(const real_t *__restrict__ coarse, int Nc, int local_row, const unsigned (&col)[3])
+{
+    Coarse3 c;
+    const char *b = reinterpret_cast<const char *>(coarse + (size_t)local_row * Nc);
+    c.v[0] = *reinterpret_cast<const real_t *>(b + col[0]);
+    c.v[1] = *reinterpret_cast<const real_t *>(b + col[1]);
+    c.v[2] = *reinterpret_cast<const real_t *>(b + col[2]);
     return c;
 }
 
@@ -227,6 +270,7 @@ template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
+    static_assert(PF + S + 2 <= 8 && 8 % (2 * PF) == 0, "the F ring has 8 slots");
     constexpr int W = 64 * COLS;
     constexpr int H = Halo<S, RESTRICT>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
@@ -257,37 +301,68 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const int av_hi = p.row_base + p.rows_local < N ? p.row_base + p.rows_local : N;
 
     const int xl = own_x0 - H + lane * COLS;  // this lane's first column
-    bool col_in[COLS], col_edge[COLS], col_even[COLS];
+    bool col_in[COLS], col_edge[COLS];
     bool lane_owns = true;
+    // rim columns keep their value: the update is U + q*t with q = 0.25 inside and 0 on the rim
+    real_t qc[COLS];
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
         const int x = xl + j;
         col_in[j] = x >= 0 && x < N;
         col_edge[j] = x <= 0 || x >= N - 1;
-        col_even[j] = (x & 1) == 0;
         lane_owns = lane_owns && x >= own_x0 && x < own_x0 + OW && x < N;
+        qc[j] = col_edge[j] ? real_t(0.0) : real_t(0.25);
+    }
+    // error norm (:610/:617): interior points with (row + col) even, each counted by the lane that owns it: as bit
+    // masks per lane and row parity (AND-ed onto |r|, so a NaN in a row that is not counted cannot leak in)
+    int nm_even[COLS], nm_odd[COLS];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        const bool mine = lane_owns && !col_edge[j];
+        nm_even[j] = (mine && ((xl + j) & 1) == 0) ? -1 : 0;  // even rows count even columns
+        nm_odd[j] = (mine && ((xl + j) & 1) != 0) ? -1 : 0;
     }
     const bool lane_loads = col_in[0] && col_in[COLS - 1];  // COLS == 2: N even, xl even
     const real_t dx2 = p.dx2, inv = p.inv;
     const bool nt_stores = N >= p.nt_min_n;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
+    // clamped column of this lane's loads (lanes left/right of the grid re-read a valid pair); lane offsets in
+    // bytes, see load_row
+    const unsigned col_off = (unsigned)(xl < 0 ? 0 : (xl > N - COLS ? N - COLS : xl)) * (unsigned)sizeof(real_t);
+    const unsigned col_st = (unsigned)(xl < 0 ? 0 : xl) * (unsigned)sizeof(real_t);  // stores are predicated on lane_owns: xl is in range there
+    const unsigned row_bytes = (unsigned)N * (unsigned)sizeof(real_t);
 
-    // ---- fused prolongation input: per-lane column tables, coarse row cache ----------
-    int pc_base = 0;              // coarse column of this lane's first fine column
-    bool pc_second_shift = false; // second fine column belongs to the next coarse cell
+    // ---- fused prolongation input: per-lane column tables, horizontal interpolants of two coarse rows
+    unsigned pc_col[3] = {0u, 0u, 0u};  // the lane's three coarse columns (clamped), as byte offsets
+    bool pc_second_shift = false;       // second fine column belongs to the next coarse cell
     real_t pc_hi[2] = {0.0, 0.0}, pc_lo[2] = {0.0, 0.0};
-    Coarse3 c_lo = {{0.0, 0.0, 0.0}}, c_hi = {{0.0, 0.0, 0.0}};
-    int c_row = -0x40000000;      // coarse row held in c_lo (wave-uniform); c_hi holds c_row + 1
+    // hA[j] / hB[j]: doProlongation's (c1*(c2x-f_x) + c2*(f_x-c1x)) resp. (c3*... + c4*...) of :700 for coarse
+    // rows c_row / c_row + 1 at this lane's fine column j.  They change only when the owner row advances
+    // (every other fine row), not with every fine row.
+    real_t hA[2] = {0.0, 0.0}, hB[2] = {0.0, 0.0};
+    int c_row = -0x40000000;            // coarse row behind hA (wave-uniform); hB belongs to c_row + 1
     if constexpr (IN == IN_PROLONG) {
         if (lane_loads) {
-            pc_base = p.p_ocol[xl];
+            const int pc_base = p.p_ocol[xl];
             pc_second_shift = p.p_ocol[xl + 1] != pc_base;
             pc_hi[0] = p.p_chi[xl];
             pc_lo[0] = p.p_clo[xl];
             pc_hi[1] = p.p_chi[xl + 1];
             pc_lo[1] = p.p_clo[xl + 1];
+            const int last = p.Nc - 1;
+            pc_col[0] = (unsigned)pc_base * (unsigned)sizeof(real_t);
+            pc_col[1] = (unsigned)(pc_base + 1 < last ? pc_base + 1 : last) * (unsigned)sizeof(real_t);
+            pc_col[2] = (unsigned)(pc_base + 2 < last ? pc_base + 2 : last) * (unsigned)sizeof(real_t);
         }
     }
+    auto interpolate = [&](const Coarse3 &c, real_t (&h)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool sh = j == 1 && pc_second_shift;
+            const real_t ca = sh ? c.v[1] : c.v[0], cb = sh ? c.v[2] : c.v[1];
+            h[j] = ca * pc_hi[j] + cb * pc_lo[j];
+        }
+    };
 
     // ---- fused restriction output: which coarse column this lane produces -------------
     int rc_col = -1;          // coarse column (interior) or -1
@@ -321,164 +396,214 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             if (last_col_lane) row[p.M - 1] = 0.0;
         }
     }
-
-    // register state: two-row history per level, F delay line, prefetch FIFO
-    Row<COLS> older[S + 1], newer[S + 1], fq[S + 2];
+    // the signed residual that feeds the fused restriction: r * (+-1 inside, 0 on the rim) -- the products are
+    // exact, and the sign of a rim zero cannot reach a coarse value (it is added to nonzero terms or to zeros)
+    real_t ms[COLS];
 #pragma unroll
-    for (int l = 0; l <= S; ++l)
-#pragma unroll
-        for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
-#pragma unroll
-    for (int l = 0; l <= S + 1; ++l)
-#pragma unroll
-        for (int j = 0; j < COLS; ++j) fq[l].v[j] = 0.0;
+    for (int j = 0; j < COLS; ++j) ms[j] = col_edge[j] ? real_t(0.0) : (p.d_sign < 0 ? real_t(-1.0) : real_t(1.0));
 
     const int y_first = y0 - (S + 1);                             // first input row
     const int T = (y1 - y0) + 2 * (S + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
     const int y_end = y_first + T;                                // one past the last input row
-    // clamped column of this lane's loads (lanes left/right of the grid re-read a valid pair)
-    const size_t col_off = (size_t)(xl < 0 ? 0 : (xl > N - COLS ? N - COLS : xl));
 
-    // wave-uniform per-row table entries travel through the same FIFO as the rows they
-    // belong to, so their (scalar) loads are issued PF iterations before use
-    // The FIFO has 2*PF slots and the loop body covers 2*PF rows: a slot is refilled PF rows
-    // after it was consumed, so a load never targets a register whose old value is still live.
-    // (With PF slots the compiler resolves the loop-carried slots by register copies at the
-    // back edge, which read the in-flight loads and force s_waitcnt vmcnt(0) every PF rows.)
-    constexpr int NB = 2 * PF;
-    Row<COLS> pu[NB], pf[NB];
-    Coarse3 pc[NB];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
-    int q_own[NB];                // IN_PROLONG: owner coarse row of the input row
-    real_t q_yh[NB], q_yl[NB];    // IN_PROLONG: its two row weights
-    int q_rc[NB];                 // RESTRICT: coarse row sampled at fine row (input row - S - 2)
-    real_t q_rw[NB];              // RESTRICT: its weight c
-#pragma unroll
-    for (int k = PF; k < NB; ++k) {
-#pragma unroll
-        for (int j = 0; j < COLS; ++j) pu[k].v[j] = pf[k].v[j] = 0.0;
-        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
-        q_own[k] = q_rc[k] = -1;
-        q_yh[k] = q_yl[k] = q_rw[k] = 0.0;
+    // ---- wave-uniform per-row table entries: ONE REGISTER PER TABLE, one row per lane.  Lane L of a block holds the
+    // entry of row (first row of the block) + L, a step picks its row with v_readlane; a block lasts 64 steps
+    // and the next one is loaded 8 steps before it is needed.  (Scalar loads per row -- with their guards, their
+    // address arithmetic and, above all, a FIFO of SGPR pairs that spilled -- cost far more instructions.)
+    //   prolongation: owner coarse row (needed PF steps ahead, for the coarse prefetch) and the two row weights;
+    //   restriction: coarse row sampled at fine row (input row - S - 2) and its weight c.
+    int tb_own = -1, tbn_own = -1;                          // block of the row being PREFETCHED (step + PF)
+    int tb_crow = 0, tbn_crow = 0;                          // ... and the local index of the coarse row (owner + 1), clamped
+    real_t tb_yh = 0.0, tb_yl = 0.0, tbn_yh = 0.0, tbn_yl = 0.0;  // block of the row being consumed
+    int tb_rc = -1, tbn_rc = -1;
+    real_t tb_rw = 0.0, tbn_rw = 0.0;
+    auto load_own_block = [&](int first_row) {  // -> tbn_own
+        const int y = first_row + lane;
+        const bool ok = y >= av_lo && y < av_hi && y < y_end;
+        const int yc = y < 0 ? 0 : (y < N ? y : N - 1);
+        const int v = p.p_orow[yc];
+        tbn_own = ok ? v : -1;
+        // rows fetched ahead of need may lie outside the local window of the coarse array: clamped, never consumed
+        const int r = tbn_own + 1 - p.coarse_base;
+        tbn_crow = r < 0 ? 0 : (r < p.coarse_rows - 1 ? r : p.coarse_rows - 1);
+    };
+    auto load_weight_block = [&](int first_row) {  // -> tbn_yh, tbn_yl
+        const int y = first_row + lane;
+        const int yc = y < 0 ? 0 : (y < N ? y : N - 1);
+        tbn_yh = p.p_rhi[yc];
+        tbn_yl = p.p_rlo[yc];
+    };
+    auto load_restrict_block = [&](int first_row) {  // -> tbn_rc, tbn_rw; rows outside the chunk sample nothing
+        const int y = first_row + lane;
+        const bool ok = y >= y0 && y < y1;
+        const int yc = y < 0 ? 0 : (y < N ? y : N - 1);
+        const int v = p.r_inv[yc];
+        const real_t w = p.r_wf[yc];
+        tbn_rc = ok ? v : -1;
+        tbn_rw = w;
+    };
+    if constexpr (IN == IN_PROLONG) {
+        load_own_block(y_first);
+        tb_own = tbn_own;
+        tb_crow = tbn_crow;
+        load_weight_block(y_first);
+        tb_yh = tbn_yh;
+        tb_yl = tbn_yl;
     }
+    if constexpr (RESTRICT) {
+        load_restrict_block(y_first - (S + 2));
+        tb_rc = tbn_rc;
+        tb_rw = tbn_rw;
+    }
+
+    // register state: two-row history per level; F rows live in a ring of 8 (row t in slot t % 8: loaded at step
+    // t - PF, read by level l at step t + l, by the residual at step t + S + 1); U rows in a ring of 2*PF.  The loop
+    // body covers 8 steps, a multiple of every ring, so every slot index is a compile-time constant and nothing is
+    // ever copied from slot to slot; a load never targets a register whose old value is still live.
+    Row<COLS> older[S + 1], newer[S + 1];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) {
-        const int y = y_first + k;
-        const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
-        const int yc = y < av_lo ? av_lo : (y < av_hi ? y : av_hi - 1);  // clamped into the window
-        const size_t off = (size_t)(yc - p.row_base) * N + col_off;
-        if constexpr (IN != IN_ZERO) pu[k] = load_row<COLS>(p.in + off);
-        pf[k] = load_row<COLS>(p.F + off);
+    for (int l = 0; l <= S; ++l)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
+    constexpr int NB = 8, NU = 2 * PF;
+    Row<COLS> fr[NB], pu[NU];
+    Coarse3 pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
+    int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) fr[k].v[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) pu[k].v[j] = 0.0;
+        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
         q_own[k] = -1;
-        q_yh[k] = q_yl[k] = q_rw[k] = 0.0;
-        q_rc[k] = -1;
-        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
-        if constexpr (IN == IN_PROLONG) {
-            if (row_ok) {
-                q_own[k] = table_i(p.p_orow, y);
-                q_yh[k] = table_d(p.p_rhi, y);
-                q_yl[k] = table_d(p.p_rlo, y);
-            }
-            // the UPPER coarse row of this input row travels with it through the FIFO, so every
-            // vector load of the loop is issued at a fixed place PF iterations before its use
-            pc[k] = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, q_own[k] + 1, pc_base);
-        }
-        if constexpr (RESTRICT) {
-            const int yl = y - S - 2;
-            if (yl >= y0 && yl < y1) {
-                q_rc[k] = table_i(p.r_inv, yl);
-                q_rw[k] = table_d(p.r_wf, yl);
-            }
-        }
     }
+
+    // wave-uniform row addresses, in bytes.  The load address follows the CLAMPED input row (every load is issued, see
+    // load_row): it moves on only while the next row lies inside the window; the store address follows the unclamped
+    // output row (stores are predicated).
+    const char *in_b = reinterpret_cast<const char *>(p.in), *f_b = reinterpret_cast<const char *>(p.F);
+    const int yc_first = y_first < av_lo ? av_lo : (y_first < av_hi ? y_first : av_hi - 1);
+    unsigned long long ld_off = (unsigned long long)(yc_first - p.row_base) * row_bytes;  // row of the next load
+    int ld_t = 0;                                                                          // its step index (row y_first + ld_t)
+    long long st_off = (long long)(y_first - S - p.row_base) * (long long)row_bytes;       // row yin - S of the current step
+    const unsigned inner_rows = (unsigned)(av_hi - av_lo - 1);
+
+    // issue the loads of input row y_first + ld_t into their ring slots (u8 = ld_t % 8, compile-time at every call)
+    auto fetch = [&](int u8) {
+        if constexpr (IN != IN_ZERO) pu[u8 % NU] = load_row<COLS>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
+        fr[u8] = load_row<COLS>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
+        if constexpr (IN == IN_PROLONG) {
+            // the UPPER coarse row of this input row travels with it, so every vector load of the loop is issued at
+            // a fixed place PF steps before its use
+            q_own[u8 % NU] = lane_value(tb_own, ld_t & 63);
+            pc[u8 % NU] = load_coarse_local(p.coarse, p.Nc, lane_value(tb_crow, ld_t & 63), pc_col);
+        }
+        ++ld_t;
+        // the clamped row moves on only inside the window: av_lo < y_first + ld_t < av_hi
+        ld_off += ((unsigned)(y_first + ld_t - av_lo - 1) < inner_rows) ? row_bytes : 0u;
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) fetch(k);
 
     if constexpr (IN == IN_PROLONG) {
-        // before the first rotation c_hi must hold the owner row of the first input row
+        // before the first rotation hB must belong to the owner row of the first input row
         const int ys = y_first > av_lo ? y_first : av_lo;
         if (ys < av_hi && ys < y_end) {
             const int i0 = table_i(p.p_orow, ys);
-            c_hi = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_base);
+            const Coarse3 c0 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
+            interpolate(c0, hB);
             c_row = i0 - 1;
         }
     }
 
     double acc = 0.0;
+    const unsigned rows_own = (unsigned)(y1 - y0), rows_norm = (unsigned)(p.norm_y1 - p.norm_y0);
+    // the loop body covers 8 rows, so the parity of the residual row is a compile-time property of the position in
+    // the body once the parity of the chunk's first residual row is folded into the masks
+    int nm_k0[COLS], nm_k1[COLS];  // masks of the residual rows at even / odd positions k
+    {
+        const bool first_odd = ((y_first - S - 1) & 1) != 0;
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            nm_k0[j] = first_odd ? nm_odd[j] : nm_even[j];
+            nm_k1[j] = first_odd ? nm_even[j] : nm_odd[j];
+        }
+    }
 
     for (int t0 = 0; t0 < T; t0 += NB) {
+        // table blocks: (t0 & 63) == 56 -> load the blocks that start 8 steps from now; == 0 -> they take over.
+        // The owner block runs PF steps ahead of the others (it serves the prefetch), so it switches inside the body.
+        if ((t0 & 63) == 56) {
+            if constexpr (IN == IN_PROLONG) {
+                load_own_block(y_first + t0 + 8);
+                load_weight_block(y_first + t0 + 8);
+            }
+            if constexpr (RESTRICT) load_restrict_block(y_first + t0 + 8 - (S + 2));
+        }
+        if ((t0 & 63) == 0 && t0 > 0) {
+            if constexpr (IN == IN_PROLONG) {
+                tb_yh = tbn_yh;
+                tb_yl = tbn_yl;
+            }
+            if constexpr (RESTRICT) {
+                tb_rc = tbn_rc;
+                tb_rw = tbn_rw;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int kr = (k + PF) % NB;   // the slot refilled while slot k is consumed
-            const int yin = y_first + t0 + k;
-            Row<COLS> nw, cf = pf[k];
+            const int t = t0 + k;
+            if (k > 0 && t >= T) break;  // (small levels: a chunk is a dozen rows, not a multiple of 8)
+            const int yin = y_first + t;
+            Row<COLS> nw;
             if constexpr (IN == IN_ZERO) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) nw.v[j] = 0.0;
             } else {
-                nw = pu[k];
+                nw = pu[k % NU];
             }
-            const int own_i = q_own[k];
-            const real_t own_yh = q_yh[k], own_yl = q_yl[k];
-            const Coarse3 own_up = pc[k];
-            const int rc_row = q_rc[k];
-            const real_t rc_w = q_rw[k];
-            {   // refill the slot consumed PF rows ago with the row PF ahead
-                const int y = yin + PF;
-                const bool row_ok = y >= av_lo && y < av_hi && y < y_end;
-                const int yc = y < av_lo ? av_lo : (y < av_hi ? y : av_hi - 1);
-                const size_t off = (size_t)(yc - p.row_base) * N + col_off;
-                if constexpr (IN != IN_ZERO) pu[kr] = load_row<COLS>(p.in + off);
-                pf[kr] = load_row<COLS>(p.F + off);
-                if constexpr (IN == IN_PROLONG) {
-                    q_own[kr] = -1;
-                    if (row_ok) {
-                        q_own[kr] = table_i(p.p_orow, y);
-                        q_yh[kr] = table_d(p.p_rhi, y);
-                        q_yl[kr] = table_d(p.p_rlo, y);
-                    }
-                    pc[kr] = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, q_own[kr] + 1, pc_base);
-                }
-                if constexpr (RESTRICT) {
-                    const int yl = y - S - 2;
-                    q_rc[kr] = -1;
-                    if (yl >= y0 && yl < y1) {
-                        q_rc[kr] = table_i(p.r_inv, yl);
-                        q_rw[kr] = table_d(p.r_wf, yl);
-                    }
+            const int own_i = q_own[k % NU];
+            const Coarse3 own_up = pc[k % NU];
+            if constexpr (IN == IN_PROLONG) {
+                // the prefetch below reads the owner of row t + PF: from step 64 m - PF on that is the next block
+                if (k == NB - PF && (t0 & 63) == 56) {
+                    tb_own = tbn_own;
+                    tb_crow = tbn_crow;
                 }
             }
+            fetch((k + PF) % NB);  // the row PF ahead, into the slots whose rows were retired (k + PF - 8 resp. k - PF)
 
             if constexpr (IN == IN_PROLONG) {
                 // level 0 = U + P(coarse): doProlongation :700 as a gather, then
                 // doGridAddition :569 (U1 = U1 + U2).  own_i is wave-uniform.
                 if (own_i >= 0) {
                     if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
-                        c_lo = c_hi;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) hA[j] = hB[j];
                         c_row = own_i;
+                        interpolate(own_up, hB);  // row own_i + 1, loaded PF iterations ago
                     }
-                    c_hi = own_up;         // row own_i + 1, loaded PF iterations ago
+                    const real_t own_yh = lane_value(tb_yh, t & 63), own_yl = lane_value(tb_yl, t & 63);
                     const real_t c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
 #pragma unroll
                     for (int j = 0; j < COLS; ++j) {
-                        const bool sh = j == 1 && pc_second_shift;
-                        const real_t c1 = sh ? c_lo.v[1] : c_lo.v[0], c2 = sh ? c_lo.v[2] : c_lo.v[1];
-                        const real_t c3 = sh ? c_hi.v[1] : c_hi.v[0], c4 = sh ? c_hi.v[2] : c_hi.v[1];
-                        const real_t xh = pc_hi[j], xlo = pc_lo[j];
-                        const real_t num = (c1 * xh + c2 * xlo) * own_yh + (c3 * xh + c4 * xlo) * own_yl;
+                        const real_t num = hA[j] * own_yh + hB[j] * own_yl;
                         const real_t pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
                         nw.v[j] = nw.v[j] + pv;
                     }
                 }
             }
 
-#pragma unroll
-            for (int l = S + 1; l >= 1; --l) fq[l] = fq[l - 1];
-            fq[0] = cf;
-
             // levels 1..S: level l produces row yin-l from level l-1 rows yin-l-1, yin-l, yin-l+1
 #pragma unroll
             for (int l = 1; l <= S; ++l) {
                 const int y = yin - l;
-                const bool row_edge = y <= 0 || y >= N - 1;
+                const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;  // 0 on the rim rows 0 and N-1
                 const Row<COLS> c = newer[l - 1], so = older[l - 1];
+                const Row<COLS> &f = fr[(k - l + NB) % NB];
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> o;
@@ -488,13 +613,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     const real_t e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
                     // src/MG_solver_CPU.cpp:590: U += 0.25*(U[i+1]+U[i-1]+U[j+1]+U[j-1] - 4U - dx^2 F)
                     // `- 4*U` through one fma: 4*U is exact, so fma(-4, U, a) is the same bits as a - 4*U (one VALU op less)
-                    const real_t t = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - dx2 * fq[l].v[j];
-                    o.v[j] = c.v[j] + real_t(0.25) * t;
+                    const real_t t4 = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - dx2 * f.v[j];
+                    // `U + 0.25*t` through one fma as well: the product with a power of two is exact, so the fused form
+                    // rounds once exactly like the sum does; with q = 0 on the rim (row or column) the point keeps its
+                    // value, which replaces the rim selects
+                    o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), t4, c.v[j]);
                 }
-                // the rim keeps its value: ONE select per value on the merged condition (the compiler turns the
-                // two nested wave-uniform cases into two selects per value otherwise: 12 more VALU ops per row)
-#pragma unroll
-                for (int j = 0; j < COLS; ++j) o.v[j] = (row_edge || col_edge[j]) ? c.v[j] : o.v[j];
                 older[l - 1] = c;
                 newer[l - 1] = nw;
                 nw = o;
@@ -503,15 +627,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // nw is level S of row yin-S: the smoothed U
             {
                 const int y = yin - S;
-                if (y >= y0 && y < y1 && lane_owns) {
+                if ((unsigned)(y - y0) < rows_own && lane_owns) {
                     if (sizeof(real_t) != sizeof(double) && p.out_wide) {
                         // mixed precision: the last node of a cycle hands its result over in fp64 (exact
                         // widening) instead of leaving it to a separate conversion pass
-                        double *w = p.out_wide + (size_t)(y - p.row_base) * N + xl;
+                        double *w = reinterpret_cast<double *>(reinterpret_cast<char *>(p.out_wide) + 2 * st_off + 2u * col_st);  // 8 B per element here
 #pragma unroll
                         for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
                     } else {
-                        store_row<COLS>(p.out + (size_t)(y - p.row_base) * N + xl, nw, nt_stores);
+                        store_row<COLS>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.out) + st_off), col_st, nw, nt_stores);
                     }
                 }
             }
@@ -519,10 +643,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // residual stage, row yin-S-1 (src/MG_solver_CPU.cpp:560 and the error sums :611)
             if (want_res) {
                 const int y = yin - S - 1;
-                const bool mine = y >= y0 && y < y1 && lane_owns;  // each point counted once
-                const bool counted = mine && y >= p.norm_y0 && y < p.norm_y1;
-                const bool row_edge = y <= 0 || y >= N - 1;
+                const bool mine_row = (unsigned)(y - y0) < rows_own;  // each point counted once
+                const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;
+                const int cm = (mine_row && (unsigned)(y - p.norm_y0) < rows_norm) ? inner : 0;  // -1: the row counts
                 const Row<COLS> c = newer[S], so = older[S];
+                const Row<COLS> &f = fr[(k - S - 1 + NB) % NB];
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> d;
@@ -530,42 +655,46 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 for (int j = 0; j < COLS; ++j) {
                     const real_t w = j == 0 ? west0 : c.v[j > 0 ? j - 1 : 0];
                     const real_t e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
-                    const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - fq[S + 1].v[j];
-                    const bool interior = !(row_edge || col_edge[j]);
-                    const real_t dv = interior ? r : real_t(0.0);
-                    d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
-                    // (row+col) even interior points only, :610/:617
-                    if (counted && interior && (((y & 1) == 0) == col_even[j])) acc += fabs((double)r);  // norms are accumulated in fp64 whatever the field type
+                    const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - f.v[j];
+                    if constexpr (RESTRICT) {
+                        d.v[j] = r * hi_bits_and(ms[j], inner);  // sign flip :277-280 and the zero rim in one exact product
+                    } else {
+                        const real_t dv = (inner != 0 && !col_edge[j]) ? r : real_t(0.0);
+                        d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
+                    }
+                    // (row+col) even interior points only, :610/:617; norms are accumulated in fp64 whatever the field type
+                    const int am = ((k & 1) ? nm_k1[j] : nm_k0[j]) & cm;
+                    acc += fabs(bits_and((double)r, am));
                 }
-                if (mine && p.D) store_row<COLS>(p.D + (size_t)(y - p.row_base) * N + xl, d, nt_stores);
+                if (mine_row && lane_owns && p.D)
+                    store_row<COLS>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, d, nt_stores);
 
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
                     // rc has its lower-left sample in fine row y-1
-                    // (rc_row / rc_w came through the FIFO: wave-uniform, -1 = no coarse row has its
-                    // lower-left sample in fine row y-1 of this chunk)
-                    {
-                        if (rc_row >= 0) {
-                            const real_t wc = rc_w, wd = real_t(1.0) - wc;  // c, d of :664-666
-                            const real_t p_up = from_lane_above(d_prev.v[0]);
-                            const real_t q_up = from_lane_above(d.v[0]);
-                            const real_t u0 = rc_shift ? d_prev.v[1] : d_prev.v[0];
-                            const real_t u1 = rc_shift ? p_up : d_prev.v[1];
-                            const real_t u2 = rc_shift ? d.v[1] : d.v[0];
-                            const real_t u3 = rc_shift ? q_up : d.v[1];
-                            // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
-                            const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
-                            real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
-                            if (rc_col >= 0) crow[rc_col] = vc;
-                            if (first_col_lane) crow[0] = 0.0;
-                            if (last_col_lane) crow[p.M - 1] = 0.0;
-                        }
+                    // (rc_row / rc_w: wave-uniform, -1 = no coarse row has its lower-left sample in fine row y-1 of this chunk)
+                    const int rc_row = lane_value(tb_rc, t & 63);
+                    if (rc_row >= 0) {
+                        const real_t wc = lane_value(tb_rw, t & 63), wd = real_t(1.0) - wc;  // c, d of :664-666
+                        const real_t p_up = from_lane_above(d_prev.v[0]);
+                        const real_t q_up = from_lane_above(d.v[0]);
+                        const real_t u0 = rc_shift ? d_prev.v[1] : d_prev.v[0];
+                        const real_t u1 = rc_shift ? p_up : d_prev.v[1];
+                        const real_t u2 = rc_shift ? d.v[1] : d.v[0];
+                        const real_t u3 = rc_shift ? q_up : d.v[1];
+                        // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
+                        const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
+                        real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
+                        if (rc_col >= 0) crow[rc_col] = vc;
+                        if (first_col_lane) crow[0] = 0.0;
+                        if (last_col_lane) crow[p.M - 1] = 0.0;
                     }
                     d_prev = d;
                 }
             }
             older[S] = newer[S];
             newer[S] = nw;
+            st_off += row_bytes;
         }
     }
     if (p.part) {

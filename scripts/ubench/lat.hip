@@ -7,7 +7,14 @@
 #include <vector>
 
 #define REP 256
-__device__ __forceinline__ long long now() { return __builtin_readcyclecounter(); }
+// the clock read must not move across the measured chain: tie it to the chain's value through inline asm
+__device__ __forceinline__ long long now(double &x)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x)::"memory");
+    long long t = __builtin_readcyclecounter();
+    asm volatile("s_nop 0" : "+v"(x), "+s"(t)::"memory");
+    return t;
+}
 
 __device__ __forceinline__ double dpp_shr1(double v)
 {
@@ -36,35 +43,35 @@ __global__ void k_lat(double *out, long long *t, double seed, int lane_n)
     long long t0, t1;
     int slot = 0;
     // (0) dependent v_add_f64
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) x = x + y;
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (1) dependent v_mul_f64
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) x = x * y;
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (2) dependent DPP shift (2 movs) + add
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) x = x + dpp_shr1(x);
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (3) dependent ds_bpermute (2 dwords) + add
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) x = x + __shfl(x, lane_n, 64);
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (4) dependent permlane16_swap pair + add
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) {
         union { double d; int i[2]; } a, b;
@@ -76,41 +83,42 @@ __global__ void k_lat(double *out, long long *t, double seed, int lane_n)
         a.i[1] = r1[1];
         x = x + a.d;
     }
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (5) dependent LDS write + read (own wave's slots, other lane)
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) {
         sh[threadIdx.x] = x;
         x = x + sh[(threadIdx.x & ~63) + lane_n];
     }
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (6) s_barrier with all waves of the block
-    t0 = now();
+    t0 = now(x);
 #pragma unroll 16
     for (int i = 0; i < REP; ++i) __syncthreads();
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (7) independent v_add_f64 stream (issue rate)
     double a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP / 8; ++i) {
         a0 += y; a1 += y; a2 += y; a3 += y; a4 += y; a5 += y; a6 += y; a7 += y;
     }
-    t1 = now();
+    x = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     // (8) ror8 DPP + add dependent
-    t0 = now();
+    t0 = now(x);
 #pragma unroll
     for (int i = 0; i < REP; ++i) x = x + dpp_ror8(x);
-    t1 = now();
+    t1 = now(x);
     if (threadIdx.x == 0) t[slot] = t1 - t0;
     ++slot;
     out[threadIdx.x] = x + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;

@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void k(const double2_t* __restrict__ a, const 
         if (MODE == 2) acc += a[i] + b[i];
         if (MODE == 3) c[i] = acc;
         if (MODE == 4) __builtin_nontemporal_store(a[i] + b[i], &c[i]);
+        if (MODE == 5) __builtin_nontemporal_store(__builtin_nontemporal_load(&a[i]), &c[i]);
+        if (MODE == 6) __builtin_nontemporal_store(__builtin_nontemporal_load(&a[i]) + __builtin_nontemporal_load(&b[i]), &c[i]);
     }
     if (MODE == 2 && acc.x == 123.456) *sink = acc;
 }
@@ -25,10 +27,11 @@ int main()
     hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&c, n * 16); hipMalloc(&sink, 16);
     hipMemset(a, 0, n * 16); hipMemset(b, 0, n * 16); hipMemset(c, 0, n * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[] = {"copy 1R1W", "add 2R1W", "rd2 2R0W", "wr 0R1W", "add 2R1W nt-store"};
-    const double bytes[] = {32, 48, 32, 16, 48};
-    for (int grid : {2048, 8192, 65536}) {
-        for (int mode = 0; mode < 5; ++mode) {
+    const char* names[] = {"copy 1R1W", "add 2R1W", "rd2 2R0W", "wr 0R1W", "add 2R1W nt-store", "copy nt-load nt-store", "add nt-loads nt-store"};
+    const double bytes[] = {32, 48, 32, 16, 48, 32, 48};
+    // grid n/256: one 16 B element per thread, no loop (the shape of a one-row-per-block kernel)
+    for (int grid : {2048, 8192, 65536, (int)(n / 256)}) {
+        for (int mode = 0; mode < 7; ++mode) {
             float best = 1e9;
             for (int rep = 0; rep < 6; ++rep) {
                 hipEventRecord(e0);
@@ -37,6 +40,8 @@ int main()
                 if (mode == 2) k<2><<<grid, 256>>>(a, b, c, n, sink);
                 if (mode == 3) k<3><<<grid, 256>>>(a, b, c, n, sink);
                 if (mode == 4) k<4><<<grid, 256>>>(a, b, c, n, sink);
+                if (mode == 5) k<5><<<grid, 256>>>(a, b, c, n, sink);
+                if (mode == 6) k<6><<<grid, 256>>>(a, b, c, n, sink);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep > 0 && ms < best) best = ms;
