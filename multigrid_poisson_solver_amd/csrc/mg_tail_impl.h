@@ -301,6 +301,105 @@ __device__ void gauss_seidel_wave(int N, double h2, double inv, int src, int F, 
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same solve for the 8 x 8 coarsest grid of every 2^k hierarchy (and the 4 x 4 / 6 x 6 ones) by wave 0 alone,
+// WITHOUT the LDS crossbar and without a full norm in most iterations.  A W-cycle runs this solve hundreds of times
+// (512 at N = 8192) at ~76 iterations each, and a lone wave is bound by its own instruction stream (measured,
+// scripts/ubench/lat.hip: a dependent fp64 add 4.3 cycles, a 2-dword DPP shift ~16, a ds_bpermute round trip 77-115
+// cycles): the iteration of mg_gs_wave.h costs ~480 cycles -- two ds_bpermute round trips and, every iteration, a
+// residual on 64 lanes with a 6-step reduction.  Here
+//   * the 6 x 6 interior is held as 3 x 3 blocks of 2 x 2 points, one block per lane (lane = 4*block_row +
+//     block_col, column 3 is a zero dummy), so that every neighbour is either in the lane's own registers or ONE
+//     in-row DPP shift away (row_shr/shl:1 east-west, :4 north-south; dummy lanes and the lanes past the last block
+//     row supply the rim zeros).  a, d are the red points of a block, b, c the black ones -- the same in every lane,
+//     so there is no per-lane colour select either;
+//   * the reference tests `err > target_error` after every sweep (:996), err = sum|r|/(N-2)^2 (:1051-1059).  The
+//     shifted values the NEXT red pass needs are exactly the neighbours of the red points of this iterate, so the
+//     residuals of the two red points of every lane cost 12 more flops; their sum is a LOWER bound of the norm's
+//     sum.  While some lane's bound exceeds twice the target (the factor 2 swallows the rounding of the real
+//     summation many times over) the answer of the full test is known to be "go on" and the full norm -- the black
+//     residuals and the reduction -- is skipped; near convergence (the last ~10 iterations) the full norm runs
+//     every iteration.  The iterates, the stopping iteration and the result are those of the reference.
+// (A version that published every iterate to the other 15 waves for judging was measured slower than the lone-wave
+// solver it replaced: every LDS operation costs the latency-critical wave 40-100 cycles.)
+template <int CTRL>
+__device__ __forceinline__ double gsp_shift(double v)  // in-row DPP shift, zero fill
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
+
+// wave 0 solves, the other waves wait at the closing barrier; N even, 4 <= N <= 8
+__device__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F, double tol, int *state)
+{
+    const int tid = threadIdx.x;
+    if (tid < N * N) SRC(tid) = real_t(0.0);        // the rim (and, for now, everything else)
+    if (tid < 16) {                                 // the 16 lanes of DPP row 0 carry the blocks
+        const int lane = tid;
+        const int nb = (N - 2) >> 1;                // blocks per side
+        const int br = lane >> 2, bc = lane & 3;
+        const bool active = br < nb && bc < nb;
+        const int r0 = 1 + 2 * br, c0 = 1 + 2 * bc;
+        const int p00 = r0 * N + c0;
+        double fa = 0.0, fb = 0.0, fc = 0.0, fd = 0.0;
+        if (active) {
+            fa = (double)FF(p00);
+            fb = (double)FF(p00 + 1);
+            fc = (double)FF(p00 + N);
+            fd = (double)FF(p00 + N + 1);
+        }
+        const double ha = h2 * fa, hb = h2 * fb, hc = h2 * fc, hd = h2 * fd;
+        const double q = active ? 0.25 : 0.0;       // lanes without a block stay zero: they ARE the rim
+        const double keep = active ? 1.0 : 0.0;
+        const double denom = (double)((N - 2) * (N - 2));
+        // `sum/denom > tol` without the division wherever rounding cannot matter (see gsw::solve)
+        const double thr = tol * denom, thr_hi = thr * (1.0 + 0x1p-48), thr_lo = thr * (1.0 - 0x1p-48), thr_sure = 2.0 * thr;
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;  // memset(U, 0)  :993
+        double b_w = 0.0, c_s = 0.0, c_e = 0.0, b_n = 0.0;  // lane-1's b, lane-4's c, lane+1's c, lane+4's b
+        int iterations = 0;
+        for (;;) {
+            // red :1020  U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F): west + east + north + south, as mg_gs_wave.h
+            a = q * (b_w + b + c + c_s - ha);
+            d = q * (c + c_e + b_n + b - hd);
+            const double a_e = gsp_shift<0x101>(a), d_s = gsp_shift<0x114>(d), d_w = gsp_shift<0x111>(d), a_n = gsp_shift<0x104>(a);
+            // black :1043
+            b = q * (a + a_e + d + d_s - hb);
+            c = q * (d_w + d + a_n + a - hc);
+            ++iterations;
+            b_w = gsp_shift<0x111>(b);
+            c_s = gsp_shift<0x114>(c);
+            c_e = gsp_shift<0x101>(c);
+            b_n = gsp_shift<0x104>(b);
+            // residuals of the red points (:560): inv*(n + s + e + w - 4u) - f
+            const double ra = inv * (c + c_s + b + b_w - 4 * a) - fa;
+            const double rd = inv * (b_n + b + c_e + c - 4 * d) - fd;
+            const double part = keep * (fabs(ra) + fabs(rd));
+            if (iterations < 50000000 && __builtin_amdgcn_ballot_w64(part > thr_sure) != 0) continue;  // sum >= part > 2*thr: err > tol
+            const double rb = inv * (d + d_s + a_e + a - 4 * b) - fb;
+            const double rc = inv * (a_n + a + d + d_w - 4 * c) - fc;
+            double acc = keep * (fabs(ra) + fabs(rb) + fabs(rc) + fabs(rd));
+            acc += gsw::row_shr_zero<1>(acc);
+            acc += gsw::row_shr_zero<2>(acc);
+            acc += gsw::row_shr_zero<4>(acc);
+            acc += gsw::row_shr_zero<8>(acc);       // lane 15 holds the total
+            const double sum = gsw::read_lane(acc, 15);
+            const bool above = sum > thr_hi ? true : (sum < thr_lo ? false : sum / denom > tol);  // :1059, :996
+            if (!above || iterations >= 50000000) break;
+        }
+        if (active) {
+            SRC(p00) = (real_t)a;
+            SRC(p00 + 1) = (real_t)b;
+            SRC(p00 + N) = (real_t)c;
+            SRC(p00 + N + 1) = (real_t)d;
+        }
+        if (lane == 0) {
+            state[0] = 1;
+            state[1] = iterations;
+        }
+    }
+    __syncthreads();
+}
+
 // offset of level l's three arrays (U, partner, F) in the LDS array
 __device__ __forceinline__ int level_base(const TailArgsT<real_t> &a, int l)
 {
@@ -443,7 +542,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             ++cur;
         } else if (nd.type == 0) {
             const int N = a.N[cur];
-            if (N * N <= 64) {
+            if (N * N <= 64 && (N & 1) == 0 && N >= 4) {
+                gauss_seidel_blocks(N, a.gs_h2[cur], a.gs_inv[cur], U_of(cur), F_of(cur), nd.tol, a.gs_state);
+            } else if (N * N <= 64) {
                 gauss_seidel_wave(N, a.gs_h2[cur], a.gs_inv[cur], U_of(cur), F_of(cur), nd.tol, a.gs_state);
             } else if (N * N <= 64 * GS_WAVE_PTS) {
                 // fp64 fields: the level's own U array is the solver's array; fp32 fields: the fp64 scratch
@@ -520,7 +621,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
 
 // LDS layout: level arrays | (fp32 fields) fp64 scratch of the block exact solver | real tables | int tables
 struct TailLayout {
-    int tab_real0, tab_int0;
+    int tab_real0, tab_int0, gs_ring0;
     size_t bytes;
 };
 inline TailLayout tail_layout(const TailArgsT<real_t> &a)
@@ -548,6 +649,7 @@ inline TailLayout tail_layout(const TailArgsT<real_t> &a)
     bytes += (n_real * sizeof(real_t) + 7) / 8 * 8;
     L.tab_int0 = (int)(bytes / sizeof(int));
     bytes += n_int * sizeof(int);
+    L.gs_ring0 = -1;
     L.bytes = bytes;
     return L;
 }
@@ -564,6 +666,7 @@ inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
     TailArgsT<real_t> b = a;
     b.tab_real0 = L.tab_real0;
     b.tab_int0 = L.tab_int0;
+    b.gs_ring0 = L.gs_ring0;
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(TAIL_THREADS), L.bytes, s, b);
 }
 

@@ -9,7 +9,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu $@"
+# the profiler's tool library belongs to the ROCm installation: bind the engine to that HIP runtime, not to the copy
+# a PyTorch wheel bundles (multigrid_poisson_solver_amd/__init__.py:_bind_hip_runtime)
+export MG_HIP_RUNTIME=system
+ARGS="--steps 10 --warmup 2 --no-cpu --no-strong $@"
 # 1. kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 # 2./3. HBM counters, one pass each (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)

@@ -123,6 +123,12 @@ for k in set(rd) | set(wr):
     w = 1024 * wr.get(k, (0, 0))[0]
     if r + w > 1e6:
         traffic[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w, "launches": max(rd.get(k, (0, 0))[1], wr.get(k, (0, 0))[1])}
+import hashlib
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multigrid_poisson_solver_amd", "lib", "libmgpoisson.so")
+h = hashlib.sha256()
+with open(lib, "rb") as f:
+    for blk in iter(lambda: f.read(1 << 20), b""):
+        h.update(blk)
 with open(os.path.join(out_dir, "traffic.json"), "w") as f:
-    json.dump({"tag": tag, "note": "HBM bytes per launch of the finest-level launches; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB->B; separate --pmc passes",
+    json.dump({"tag": tag, "lib_sha": h.hexdigest()[:16], "note": "HBM bytes per launch of the finest-level launches; FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB->B; separate --pmc passes",
                "kernels": traffic}, f, indent=1)

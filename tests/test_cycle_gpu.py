@@ -89,6 +89,23 @@ def test_generated_wcycle_full_depth_vs_oracle(mg, oracle, tmp_path):
     want = oracle.run_cycle_file(path)
     plan = mg.CyclePlan(path, fused=True)
     check_against(plan.execute(fetch_U=True), want, zero_sign=True)
+    # the 8 x 8 solves run inside the coarse-tail kernel, pipelined over its waves (sweeper + judges): same iterates,
+    # same stopping iteration as the reference's `while (err > target_error)` (the last solve's count is left behind)
+    assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    plan.close()
+
+
+@pytest.mark.parametrize("N,n_min,tol", [(64, 8, 1e-7), (64, 8, 1e-3), (64, 8, 1e-9), (48, 6, 1e-7), (32, 4, 1e-8), (128, 8, 3e-6)])
+def test_pipelined_exact_solver_in_the_tail(mg, oracle, tmp_path, N, n_min, tol):
+    """The in-tail exact solver for even coarsest grids of at most 64 points (8 x 8, 6 x 6, 4 x 4) at several targets
+    (few iterations, many iterations): final U bit for bit and the iteration count against the oracle."""
+    path = str(tmp_path / "v.txt")
+    mg.write_vcycle_file(path, N, n_min, 2, tol)
+    want = oracle.run_cycle_file(path)
+    plan = mg.CyclePlan(path, fused=True)
+    for _ in range(2):
+        check_against(plan.execute(fetch_U=True), want, zero_sign=True)
+        assert mg.lastExactSolverIterations() == oracle.gs_iterations()
     plan.close()
 
 
