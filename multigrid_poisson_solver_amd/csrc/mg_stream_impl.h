@@ -170,13 +170,16 @@ struct Row {
 // walk costs two scalar additions instead of 64-bit vector arithmetic per lane.
 // (the lane offset is in BYTES: `uniform pointer + zero-extended 32-bit value` is the shape the instruction selector
 // needs; an element index would have to be scaled in 64 bits first)
-template <int COLS>
+#ifndef MG_NT_LOADS
+#define MG_NT_LOADS 0   // experiment: 1 = F rows, 2 = U and F rows loaded non-temporally
+#endif
+template <int COLS, bool NT = false>
 __device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ row, unsigned col_bytes)
 {
     Row<COLS> r;
     const char *a = reinterpret_cast<const char *>(row) + col_bytes;
     if constexpr (COLS == 2) {
-        const real2_t t = *reinterpret_cast<const real2_t *>(a);
+        const real2_t t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(a)) : *reinterpret_cast<const real2_t *>(a);
         r.v[0] = t.x;
         r.v[1] = t.y;
     } else {
@@ -493,8 +496,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 
     // issue the loads of input row y_first + ld_t into their ring slots (u8 = ld_t % 8, compile-time at every call)
     auto fetch = [&](int u8) {
-        if constexpr (IN != IN_ZERO) pu[u8 % NU] = load_row<COLS>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
-        fr[u8] = load_row<COLS>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
+        if constexpr (IN != IN_ZERO) pu[u8 % NU] = load_row<COLS, (MG_NT_LOADS >= 2)>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
+        fr[u8] = load_row<COLS, (MG_NT_LOADS >= 1)>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
         if constexpr (IN == IN_PROLONG) {
             // the UPPER coarse row of this input row travels with it, so every vector load of the loop is issued at
             // a fixed place PF steps before its use
