@@ -72,12 +72,16 @@ void    mg_negate(int N, double *D);
 /* ------------------------------------------------------------------------- */
 void mg_getSource(int N, double L, double *F, double min_x, double min_y);
 /* where mg_getSource (and the drivers' own getSource at load, :153) evaluates F:
- * "host" (default): libm on the host cores, chunked through 2 x 128 MiB of pinned staging -- the
- *   reference's bits, because libm's exp() is what the reference calls (:488);
- * "device": k_source on the GPU, no host pass and no PCIe; the device exp() is within 1 ulp of libm's,
- *   so F differs from the host form by at most 2 ulp and results are no longer bit-comparable with
- *   the reference (tests/test_parity_gpu.py states the measured bounds).  Also env MG_SOURCE. */
+ * "auto" (default): on the device (k_source: no host pass, no PCIe) when that reproduces THIS host's libm bit for
+ *   bit -- the reference calls libm's exp() (:488), and the device evaluates glibc's algorithm for it (table +
+ *   polynomial, FMA form); the engine compares the two on ~130k points once per process (mg_source_is_bit_identical)
+ *   and falls back to "host" when they differ (another libm, a CPU without FMA);
+ * "host": libm on the host cores, chunked through 2 x 128 MiB of pinned staging;
+ * "device": the device form unconditionally.  Also env MG_SOURCE. */
 int  mg_set_source(const char *mode);
+/* "host" or "device": what mg_getSource will use (runs the check in auto mode) */
+const char *mg_source_mode(void);
+int  mg_source_is_bit_identical(void);
 void mg_getAnalytic(int N, double L, double *U, double min_x, double min_y);
 /* sum|analytic - U| / (N*N): src/MG_solver_CPU.cpp:434-445; result to *error_host */
 void mg_analyticError(int N, double L, const double *U, double min_x, double min_y, double *error_host);

@@ -49,7 +49,8 @@ ABI = {
     "mg_get_stream": (_vp, []), "mg_sync": (None, []), "mg_last_error": (_i, []),
     "mg_last_error_string": (C.c_char_p, []), "mg_clear_error": (None, []),
     "mg_set_abort_on_error": (None, [_i]), "mg_set_smoother": (_i, [C.c_char_p]),
-    "mg_version": (C.c_char_p, []), "mg_set_source": (_i, [C.c_char_p]),
+    "mg_version": (C.c_char_p, []), "mg_set_source": (_i, [C.c_char_p]), "mg_source_mode": (C.c_char_p, []),
+    "mg_source_is_bit_identical": (_i, []),
     "mg_alloc": (_vp, [_sz]), "mg_free": (None, [_vp]), "mg_pool_trim": (None, []),
     "mg_pool_bytes": (_sz, []), "mg_upload": (None, [_vp, _vp, _sz]), "mg_download": (None, [_vp, _vp, _sz]),
     "mg_copy": (None, [_vp, _vp, _sz]), "mg_fill_zero": (None, [_vp, _sz]), "mg_negate": (None, [_i, _vp]),
@@ -202,6 +203,13 @@ def set_smoother(name):
 def set_source(mode):
     lib().mg_set_source(mode.encode())
     _check()
+
+
+def source_mode():
+    """'host' or 'device': where getSource is evaluated (auto mode: the device when it reproduces the host's libm)."""
+    m = lib().mg_source_mode().decode()
+    _check()
+    return m
 
 
 class DeviceGrid:

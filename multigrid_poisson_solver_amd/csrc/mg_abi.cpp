@@ -438,15 +438,33 @@ int mg_set_smoother(const char *name)
     }
     return 0;
 }
+}  // extern "C"
+namespace mg {
+bool source_selfcheck();
+bool source_on_device();
+}  // namespace mg
+extern "C" {
+
 int mg_set_source(const char *name)
 {
-    if (name && strcmp(name, "host") == 0) ctx().source_on_device = false;
-    else if (name && strcmp(name, "device") == 0) ctx().source_on_device = true;
+    if (name && strcmp(name, "auto") == 0) ctx().source_mode = 0;
+    else if (name && strcmp(name, "host") == 0) ctx().source_mode = 1;
+    else if (name && strcmp(name, "device") == 0) ctx().source_mode = 2;
     else {
-        fail(MG_ERR_ARG, "mg_set_source: unknown mode '%s' (host|device)", name ? name : "(null)");
+        fail(MG_ERR_ARG, "mg_set_source: unknown mode '%s' (auto|host|device)", name ? name : "(null)");
         return 1;
     }
     return 0;
+}
+const char *mg_source_mode(void)
+{
+    if (!require_ready("mg_source_mode")) return "host";
+    return source_on_device() ? "device" : "host";
+}
+int mg_source_is_bit_identical(void)
+{
+    if (!require_ready("mg_source_is_bit_identical")) return 0;
+    return source_selfcheck() ? 1 : 0;
 }
 const char *mg_version(void) { return "mgpoisson-hip 0.1 (gfx950)"; }
 
@@ -527,11 +545,41 @@ void source_rows(size_t r0, size_t r1, void *arg)
 }  // extern "C"
 
 namespace mg {
+// Does k_source (exp_libm: glibc's algorithm in its FMA form, mg_kernels.hip) reproduce THIS host's libm bit for bit?
+// Two grids (an odd one with an offset origin and a power of two), ~130k points, compared bitwise once per process.
+// A host without FMA runs another variant of glibc's exp(): the check then fails and the host form stays in charge,
+// which is that host's reference.
+bool source_selfcheck()
+{
+    Context &c = ctx();
+    if (c.source_identical >= 0) return c.source_identical == 1;
+    c.source_identical = 1;
+    const struct { int N; double L, mx, my; } cases[2] = {{257, 1.5, 0.25, -0.5}, {256, 1.0, 0.0, 0.0}};
+    for (const auto &cs : cases) {
+        const size_t n = (size_t)cs.N * cs.N;
+        std::vector<double> host(n), dev(n);
+        SourceJob job{cs.N, cs.L / (double)(cs.N - 1), cs.mx, cs.my, host.data()};
+        source_rows(0, (size_t)cs.N, &job);
+        double *d = (double *)c.pool.get(n * sizeof(double));
+        if (!d) { c.source_identical = 0; break; }
+        k::source_device(c.stream, cs.N, cs.L, d, cs.mx, cs.my, 0, cs.N);
+        mg_download(dev.data(), d, n);
+        c.pool.put(d);
+        if (memcmp(host.data(), dev.data(), n * sizeof(double)) != 0) { c.source_identical = 0; break; }
+    }
+    return c.source_identical == 1;
+}
+bool source_on_device()
+{
+    Context &c = ctx();
+    return c.source_mode == 2 || (c.source_mode == 0 && source_selfcheck());
+}
+
 void fill_source_rows(int N, double L, double min_x, double min_y, int row_lo, int row_hi, double *dev_dst)
 {
     if (row_hi <= row_lo) return;
     Context &c = ctx();
-    if (c.source_on_device) {  // mg_set_source("device"): no host pass, no PCIe; F within 2 ulp of the host form
+    if (source_on_device()) {  // no host pass, no PCIe: k_source evaluates libm's exp() algorithm on the device
         k::source_device(c.stream, N, L, dev_dst, min_x, min_y, row_lo, row_hi);
         return;
     }

@@ -91,7 +91,8 @@ struct Context {
     Pool pool;
     Pool *active_pool = nullptr;           // plan-private arena while a cycle plan executes
     Smoother smoother = SMOOTHER_STREAM;
-    bool source_on_device = false;         // mg_set_source("device"): getSource evaluated by k_source
+    int source_mode = 0;                   // mg_set_source: 0 auto (device when it reproduces the host's libm bit for bit), 1 host, 2 device
+    int source_identical = -1;             // result of the self-check: -1 not run yet, 0 differs, 1 identical
     // reduction scratch: per-block partial sums + scalar slots
     double *partials = nullptr;
     size_t partials_cap = 0;

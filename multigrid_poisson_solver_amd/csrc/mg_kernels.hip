@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mg_gs_wave.h"
+#include "mg_exp_table.h"
 #include "mg_internal.h"
 
 namespace mg {
@@ -323,8 +324,42 @@ __global__ __launch_bounds__(TB) void k_to_f64(double *__restrict__ dst, const f
 }
 
 // ---------------------------------------------------------------- problem definition
-// src/MG_solver_CPU.cpp:488 / :544.  Device exp() is within 1 ulp of libm's, so these
-// are NOT bit-identical to the host evaluation; the driver uses the host form for F.
+// src/MG_solver_CPU.cpp:488 / :544 call libm's exp().  exp_libm() evaluates it with the operations of the
+// algorithm glibc has used since 2.28 (exp(x) = 2^(k/128) * exp(r): a 128-entry table, a degree-5 polynomial),
+// in the FMA form glibc selects on every CPU with FMA: the fused multiply-adds below are the ones that build
+// performs (disassembly of libm.so.6 2.35: z + Shift, both reduction steps, every polynomial step and the final
+// scale are fused).  The table comes from scripts/gen_exp_table.py (computed from its definition), the constants
+// are the algorithm's published ones.  Nothing is assumed: mg_source_selfcheck() compares getSource on the device
+// with the host's libm bit for bit before the device form becomes the default (mg_abi.cpp).
+__device__ const uint64_t exp_tab[256] = {MG_EXP_TABLE_VALUES};
+__device__ __forceinline__ double exp_libm(double x)
+{
+    const uint32_t abstop = (uint32_t)(__double_as_longlong(x) >> 52) & 0x7ff;
+    if (abstop - 0x3c9u > 0x3eu) {
+        if (abstop < 0x3c9u) return 1.0 + x;  // |x| < 2^-54
+        return exp(x);                        // |x| >= 512: the special-case paths are not reproduced (never reached on the unit square)
+    }
+    const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52, NegLn2hiN = -0x1.62e42fefa0000p-8,
+                 NegLn2loN = -0x1.cf79abc9e3b3ap-47, C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3,
+                 C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+    const double kd_s = __builtin_fma(x, InvLn2N, Shift);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd_s);
+    const double kd = kd_s - Shift;
+    double r = __builtin_fma(kd, NegLn2hiN, x);
+    r = __builtin_fma(kd, NegLn2loN, r);
+    const unsigned idx = 2u * (unsigned)(ki & 127u);
+    const double tail = __longlong_as_double((long long)exp_tab[idx]);
+    const uint64_t sbits = exp_tab[idx + 1] + (ki << 45);
+    const double p23 = __builtin_fma(r, C3, C2);
+    const double rt = r + tail;
+    const double r2 = r * r;
+    const double p45 = __builtin_fma(r, C5, C4);
+    const double t = __builtin_fma(p23, r2, rt);
+    const double r4 = r2 * r2;
+    const double tmp = __builtin_fma(r4, p45, t);
+    const double scale = __longlong_as_double((long long)sbits);
+    return __builtin_fma(scale, tmp, scale);
+}
 // F points at grid row row0 (row slabs evaluate their own window)
 __global__ __launch_bounds__(TB) void k_source(int N, double h, double *__restrict__ F, double min_x, double min_y, int row0)
 {
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(TB) void k_source(int N, double h, double *__restri
     double v = 0.0;
     if (!rim(r, c, N)) {
         const double x = (double)c * h + min_x, y = (double)r * h + min_y;
-        v = 2.0 * x * (y - 1) * (y - 2.0 * x + x * y + 2.0) * exp(x - y);
+        v = 2.0 * x * (y - 1) * (y - 2.0 * x + x * y + 2.0) * exp_libm(x - y);
     }
     F[(size_t)blockIdx.y * N + c] = v;
 }
@@ -341,7 +376,7 @@ __device__ __forceinline__ double analytic_at(int r, int c, int N, double h, dou
 {
     if (rim(r, c, N)) return 0.0;
     const double x = (double)c * h + min_x, y = (double)r * h + min_y;
-    return exp(x - y) * x * (1.0 - x) * y * (1.0 - y);
+    return exp_libm(x - y) * x * (1.0 - x) * y * (1.0 - y);
 }
 __global__ __launch_bounds__(TB) void k_analytic(int N, double h, double *__restrict__ U, double min_x, double min_y)
 {

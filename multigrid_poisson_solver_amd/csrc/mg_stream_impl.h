@@ -273,7 +273,7 @@ template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
-    static_assert(PF + S + 2 <= 8 && 8 % (2 * PF) == 0, "the F ring has 8 slots");
+    static_assert(PF + S + 2 <= 8 && PF < 4, "the F ring has 8 slots, the U ring 4");
     constexpr int W = 64 * COLS;
     constexpr int H = Halo<S, RESTRICT>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     for (int l = 0; l <= S; ++l)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
-    constexpr int NB = 8, NU = 2 * PF;
+    constexpr int NB = 8, NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
     Row<COLS> fr[NB], pu[NU];
     Coarse3 pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
     int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
@@ -780,7 +780,11 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
     // rows in flight per lane: PF = 2 (a FIFO of 4 slots).  A deeper FIFO (PF = 3 at the same occupancy, PF = 4, 8) costs registers
     // and a longer prologue and measured slower at every size from 128 to 8192 once all loads were
     // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).
-    launch_variant<S, 2>(s, p, err_out);
+#ifndef MG_PF
+#define MG_PF 2
+#endif
+    if constexpr (S <= 3 && MG_PF == 3) launch_variant<S, 3>(s, p, err_out);
+    else launch_variant<S, 2>(s, p, err_out);
 }
 
 
