@@ -22,6 +22,8 @@
 // mixed-precision mode); with MG_REAL = double every expression is what it was before the split.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mg_divconst.h"
 #include "mg_gs_wave.h"
 #include "mg_internal.h"
@@ -80,18 +82,23 @@ extern __shared__ __align__(16) real_t lds[];
 // flat point ownership: thread t owns points t, t + 1024, ... of the level being worked on
 constexpr int PT = (TAIL_MAX_N * TAIL_MAX_N + TAIL_THREADS - 1) / TAIL_THREADS;
 
-struct Points {
-    int p[PT], r[PT], c[PT];
-    bool live[PT], inner[PT], even[PT];
+// NP = points per thread the code is instantiated for: 1 up to 32 x 32, 2 up to 45 x 45, 4 up to 64 x 64 (a level with
+// one point per thread must not pay the predicated second, third and fourth iterations of every loop: the kernel is
+// bound by its instruction count)
+template <int NP>
+struct PointsT {
+    int p[NP], r[NP], c[NP];
+    bool live[NP], inner[NP], even[NP];
 };
-__device__ __forceinline__ Points map_points(int N)
+template <int NP>
+__device__ __forceinline__ PointsT<NP> map_points(int N)
 {
-    Points P;
+    PointsT<NP> P;
     // row = floor(p / N) through one fp32 multiplication: (p + 0.5)/N is at least 0.5/N away from
     // every integer, orders of magnitude more than the rounding error at p < 4096
     const float rn = 1.0f / (float)N;
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const int p = (int)threadIdx.x + k * TAIL_THREADS;
         const int r = (int)(((float)p + 0.5f) * rn), c = p - r * N;
         P.p[k] = p;
@@ -106,11 +113,11 @@ __device__ __forceinline__ Points map_points(int N)
 
 // one Jacobi sweep src -> dst (src/MG_solver_CPU.cpp:587-599); v = this thread's own points of
 // src (kept in registers), rim keeps its value.  ZERO: src is the zero field (:256), nothing is read.
-template <bool ZERO>
-__device__ __forceinline__ void sweep(const Points &P, int N, int src, int dst, real_t (&v)[PT], const real_t (&h2f)[PT])
+template <bool ZERO, int NP>
+__device__ __forceinline__ void sweep(const PointsT<NP> &P, int N, int src, int dst, real_t (&v)[NP], const real_t (&h2f)[NP])
 {
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
+    for (int k = 0; k < NP; ++k) {
         if (!P.live[k]) continue;
         const int p = P.p[k];
         real_t nv = v[k];
@@ -489,26 +496,28 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
                 ++cur;
                 continue;
             }
+            auto down = [&](auto np_tag) {
+            constexpr int NP = decltype(np_tag)::value;
             const int F = F_of(cur);
-            const Points P = map_points(N);
+            const PointsT<NP> P = map_points<NP>(N);
             const real_t dx2 = a.dx2[cur], inv = a.inv[cur];
-            real_t v[PT], f[PT], h2f[PT];
+            real_t v[NP], f[NP], h2f[NP];
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 f[k] = P.live[k] ? lds[F + P.p[k]] : real_t(0.0);
                 h2f[k] = dx2 * f[k];
                 v[k] = 0.0;
             }
-            sweep<true>(P, N, 0, U_of(cur), v, h2f);
+            sweep<true, NP>(P, N, 0, U_of(cur), v, h2f);
             for (int s = 1; s < nd.steps; ++s) {
-                sweep<false>(P, N, U_of(cur), T_of(cur), v, h2f);
+                sweep<false, NP>(P, N, U_of(cur), T_of(cur), v, h2f);
                 swapped ^= 1u << cur;
             }
             // residual once per point: the error norm (:607-622) and, negated, the restriction's input
             const int src = U_of(cur), D = T_of(cur);
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 if (!P.live[k]) continue;
                 const int p = P.p[k];
                 real_t d = 0.0;
@@ -524,9 +533,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             parity ^= 1;
             const int M = a.N[cur + 1], Fc = F_of(cur + 1);
             const int rt = real_tab(a, cur), it = int_tab(a, cur);
-            const Points Q = map_points(M);
+            const PointsT<1> Q = map_points<1>(M);  // M <= 32: one coarse point per thread at most
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
+            for (int k = 0; k < 1; ++k) {
                 if (!Q.live[k]) continue;
                 real_t vc = 0.0;
                 if (Q.inner[k]) {
@@ -538,6 +547,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
                 }
                 lds[Fc + Q.p[k]] = vc;
             }
+            };
+            if (N * N <= TAIL_THREADS) down(std::integral_constant<int, 1>{});
+            else if (N * N <= 2 * TAIL_THREADS) down(std::integral_constant<int, 2>{});
+            else down(std::integral_constant<int, PT>{});
             __syncthreads();
             ++cur;
         } else if (nd.type == 0) {
@@ -563,15 +576,17 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
                 --cur;
                 continue;
             }
+            auto up = [&](auto np_tag) {
+            constexpr int NP = decltype(np_tag)::value;
             const int uc = U_of(cur), F = F_of(fine);
             const int rt = real_tab(a, fine) + Nc, it = int_tab(a, fine) + Nc;  // past w[M] / lo[M]
             const real_t c_dx = a.c_dx[fine], c_rcp = real_t(1.0) / c_dx, dx2 = a.dx2[fine], inv = a.inv[fine];
-            const Points P = map_points(N);
-            real_t v[PT], f[PT], h2f[PT];
+            const PointsT<NP> P = map_points<NP>(N);
+            real_t v[NP], f[NP], h2f[NP];
             {
                 const int uf = U_of(fine);
 #pragma unroll
-                for (int k = 0; k < PT; ++k) {
+                for (int k = 0; k < NP; ++k) {
                     f[k] = real_t(0.0);
                     v[k] = real_t(0.0);
                     if (P.live[k]) {
@@ -593,13 +608,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             }
             __syncthreads();
             for (int s = 0; s < nd.steps; ++s) {
-                sweep<false>(P, N, U_of(fine), T_of(fine), v, h2f);
+                sweep<false, NP>(P, N, U_of(fine), T_of(fine), v, h2f);
                 swapped ^= 1u << fine;
             }
             const int src = U_of(fine);
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
+            for (int k = 0; k < NP; ++k) {
                 if (P.inner[k] && P.even[k]) {
                     const int p = P.p[k];
                     acc += fabs((double)(inv * (SRC(p + N) + SRC(p - N) + SRC(p + 1) + SRC(p - 1) - 4 * v[k]) - f[k]));
@@ -608,6 +623,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             post_partial(acc, slots[parity]);
             __syncthreads();
             if (threadIdx.x == 0 && nd.err_slot >= 0) finish_error(slots[parity], N, a.err_dev + nd.err_slot);
+            };
+            if (N * N <= TAIL_THREADS) up(std::integral_constant<int, 1>{});
+            else if (N * N <= 2 * TAIL_THREADS) up(std::integral_constant<int, 2>{});
+            else up(std::integral_constant<int, PT>{});
             parity ^= 1;
             --cur;
         }
