@@ -172,3 +172,63 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(d["value"] - lups / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c and c["value"] > 0
+
+
+def test_exp_table_and_algorithm_reproduce_this_libm():
+    """getSource runs on the device with libm's exp() algorithm (mg_kernels.hip:exp_libm; table =
+    csrc/mg_exp_table.h, generated by scripts/gen_exp_table.py from its definition).  CPU check of both: the
+    committed header is what the generator prints, and the algorithm -- restated here with exact rational arithmetic
+    for every fused multiply-add -- returns math.exp's bits on arguments of the kind getSource produces (x - y on
+    the unit square and around it).  On a host whose libm is another one this test fails and the engine's run-time
+    self-check keeps the host form of getSource."""
+    import math
+    import re
+    import struct
+    import subprocess
+    import sys
+    from fractions import Fraction
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_exp_table.py")], capture_output=True, text=True, check=True).stdout
+    hdr = open(os.path.join(ROOT, "multigrid_poisson_solver_amd", "csrc", "mg_exp_table.h")).read()
+    assert gen == hdr
+    tab = [int(v, 16) for v in re.findall(r"0x([0-9a-f]{16})ull", hdr)]
+    assert len(tab) == 256
+
+    def f2b(x):
+        return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+    def b2f(b):
+        return struct.unpack("<d", struct.pack("<Q", b & (2 ** 64 - 1)))[0]
+
+    def fma(a, b, c):  # one rounding: float(Fraction) rounds to nearest even
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    InvLn2N, Shift = float.fromhex("0x1.71547652b82fep+7"), float.fromhex("0x1.8p+52")
+    NegLn2hiN, NegLn2loN = float.fromhex("-0x1.62e42fefa0000p-8"), float.fromhex("-0x1.cf79abc9e3b3ap-47")
+    C2, C3 = float.fromhex("0x1.ffffffffffdbdp-2"), float.fromhex("0x1.555555555543cp-3")
+    C4, C5 = float.fromhex("0x1.55555cf172b91p-5"), float.fromhex("0x1.1111167a4d017p-7")
+
+    def exp_alg(x):
+        abstop = (f2b(x) >> 52) & 0x7ff
+        if abstop < 0x3c9:
+            return 1.0 + x
+        assert abstop - 0x3c9 <= 0x3e
+        kd_s = fma(x, InvLn2N, Shift)
+        ki = f2b(kd_s)
+        kd = kd_s - Shift
+        r = fma(kd, NegLn2hiN, x)
+        r = fma(kd, NegLn2loN, r)
+        idx = 2 * (ki & 127)
+        tail, sbits = b2f(tab[idx]), tab[idx + 1] + (ki << 45)
+        p23, rt, r2, p45 = fma(r, C3, C2), r + tail, r * r, fma(r, C5, C4)
+        t = fma(p23, r2, rt)
+        tmp = fma(r2 * r2, p45, t)
+        scale = b2f(sbits)
+        return fma(scale, tmp, scale)
+
+    rng = np.random.default_rng(7)
+    args = list(rng.uniform(-1.0, 1.0, 1500)) + list(rng.uniform(-4.0, 4.0, 300)) + [0.0, -0.0, 1e-300, 0.5, -0.5, 1.0 / 8191, -2047.0 / 8191]
+    N = 129
+    h = 1.0 / (N - 1)
+    args += [c * h - r * h for r in (1, 7, 64, 127) for c in range(1, N - 1, 5)]
+    bad = [x for x in args if f2b(exp_alg(x)) != f2b(math.exp(x))]
+    assert not bad, f"{len(bad)} of {len(args)} arguments differ from math.exp, e.g. {bad[:3]}"
