@@ -997,6 +997,10 @@ int mg_cycle_main(int argc, char **argv)
         return 1;
     }
     mg_cycle_result res;
+    // MG_WARMUP=k: k untimed runs first.  A process's first window also pays for loading the code objects, the first
+    // hipMalloc of every level (the pool is empty) and the upload of the transfer tables: ~10 ms whatever the grid.
+    if (const char *w = getenv("MG_WARMUP"))
+        for (int i = 0; i < atoi(w); ++i) mg_cycle_execute(plan, &res);
     const int status = mg_cycle_execute(plan, &res);
     if (status != 0) {
         printf("[ ERROR ]: cycle structure file is malformed (status %d)\n", status);
