@@ -44,7 +44,9 @@
 // MG_REAL = double every expression is exactly what it was before the split.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "mg_divconst.h"
 #include "mg_internal.h"
@@ -86,6 +88,7 @@ struct StreamParams {
     real_t *D;          // nullptr: residual not stored
     int d_sign;
     double *part;       // nullptr: no error norm; else one partial per wave
+    long long *trace;   // MG_STREAM_TRACE builds only
     int rows_per_chunk;
     int groups;         // workgroups per chunk row
     int n_blocks;       // chunks * groups
@@ -280,6 +283,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
     // range of tiles so halo re-reads hit its L2.  Speed only, never correctness.
+#ifdef MG_STREAM_TRACE   // diagnostics: where a small launch spends its time (tile 0, wave 0 -> p.D as a scratch of 4 doubles)
+    const long long tr0 = wall_clock64();
+#endif
     const int per_xcd = (p.n_blocks + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile >= p.n_blocks) return;
@@ -522,6 +528,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         }
     }
 
+#ifdef MG_STREAM_TRACE
+    const long long tr1 = wall_clock64();
+#endif
     double acc = 0.0;
     const unsigned rows_own = (unsigned)(y1 - y0), rows_norm = (unsigned)(p.norm_y1 - p.norm_y0);
     // the loop body covers 8 rows, so the parity of the residual row is a compile-time property of the position in
@@ -700,6 +709,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             st_off += row_bytes;
         }
     }
+#ifdef MG_STREAM_TRACE
+    if (p.trace && (threadIdx.x & 63) == 0) {  // per wave: start, end of prologue, end of loop (100 MHz ticks); [0..3]: legacy record of the middle tile
+        const long long tr2 = wall_clock64();
+        long long *rec = p.trace + 8 + 4 * ((size_t)tile * WAVES_PER_WG + wave);
+        rec[0] = tr0;
+        rec[1] = tr1;
+        rec[2] = tr2;
+        rec[3] = (long long)blockIdx.x;
+        if (tile == p.n_blocks / 2 && wave == 0) {
+            p.trace[0] = tr0;
+            p.trace[1] = tr1;
+            p.trace[2] = tr2;
+            p.trace[3] = T;
+        }
+    }
+#endif
     if (p.part) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -745,6 +770,12 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     p.groups = groups;
     p.n_blocks = chunks * groups;
     p.part = nullptr;
+#ifdef MG_STREAM_TRACE
+    static long long *trace_dev = nullptr;
+    if (!trace_dev) (void)hipMalloc((void **)&trace_dev, (8 + 4 * 4 * 4096) * sizeof(long long));
+    (void)hipMemsetAsync(trace_dev, 0, (8 + 4 * 4 * 4096) * sizeof(long long), s);
+    p.trace = trace_dev;
+#endif
     const size_t n_part = (size_t)p.n_blocks * WAVES_PER_WG;
     if (err_out) {
         p.part = norm_partials(n_part);  // every wave of every tile writes its slot
@@ -752,6 +783,44 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
     hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+#ifdef MG_STREAM_TRACE
+    {
+        long long t[4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, trace_dev, sizeof t, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[stream trace] N=%d IN=%d R=%d tiles=%d rows/chunk=%d: prologue %.2f us, %lld steps %.2f us (%.3f us/step)\n", N, IN, (int)RESTRICT,
+                p.n_blocks, rows, (t[1] - t[0]) * 0.01, t[3], (t[2] - t[1]) * 0.01, (t[2] - t[1]) * 0.01 / (double)t[3]);
+        if (N >= 4096 && p.n_blocks <= 4096) {  // spread of the waves' lifetimes
+            const size_t nw = (size_t)p.n_blocks * WAVES_PER_WG;
+            std::vector<long long> all(4 * nw);
+            (void)hipMemcpy(all.data(), trace_dev + 8, all.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t_min = 0x7fffffffffffffffll, t_max = 0;
+            std::vector<double> start, life, endt;
+            for (size_t w = 0; w < nw; ++w) {
+                if (all[4 * w] == 0) continue;  // a wave past the grid's last strip left no record
+                if (all[4 * w] < t_min) t_min = all[4 * w];
+                if (all[4 * w + 2] > t_max) t_max = all[4 * w + 2];
+            }
+            double xcd_end[8] = {0}, xcd_start[8] = {0};
+            for (size_t w = 0; w < nw; ++w) {
+                if (all[4 * w] == 0) continue;
+                start.push_back((all[4 * w] - t_min) * 0.01);
+                endt.push_back((all[4 * w + 2] - t_min) * 0.01);
+                life.push_back((all[4 * w + 2] - all[4 * w]) * 0.01);
+                const int x = (int)(all[4 * w + 3] & 7);
+                if (endt.back() > xcd_end[x]) xcd_end[x] = endt.back();
+                if (start.back() > xcd_start[x]) xcd_start[x] = start.back();
+            }
+            auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            fprintf(stderr, "   waves %zu: start p50 %.1f p99 %.1f max %.1f us | lifetime p1 %.1f p50 %.1f p99 %.1f max %.1f | end p1 %.1f p50 %.1f p99 %.1f max %.1f | span %.1f us\n",
+                    nw, pct(start, .5), pct(start, .99), pct(start, 1.0), pct(life, .01), pct(life, .5), pct(life, .99), pct(life, 1.0), pct(endt, .01),
+                    pct(endt, .5), pct(endt, .99), pct(endt, 1.0), (t_max - t_min) * 0.01);
+            fprintf(stderr, "   last wave per XCD ends at:");
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", xcd_end[x]);
+            fprintf(stderr, " us\n");
+        }
+    }
+#endif
     // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
     if (err_out) norm_finish(s, p.part, n_part, p.raw_norm ? -1 : N, err_out);
 }
