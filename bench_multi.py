@@ -114,8 +114,8 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
         "N": N, "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
         "ms_per_step": round(ms_per_step, 4),
         "workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
-                    f"{len(sizes)} levels, {world} row slabs, ghost rows over RCCL on a second stream (overlapped with the interior "
-                    f"rows), levels N<={collapse_N} replicated on every rank",
+                    f"{len(sizes)} levels, {world} row slabs, communication-avoiding schedule (F halos recomputed, ONE RCCL group per "
+                    f"cycle on a second stream: collapse all-gather + one U halo), levels N<={collapse_N} replicated on every rank",
         "levels": len(sizes), "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1), "mg_error": r["mg_error"],
         "roofline": roof, "kernels": kernels[:6],
         # where rank 0's time went (live hipEvent pairs): its kernel launches, its ghost exchanges (which

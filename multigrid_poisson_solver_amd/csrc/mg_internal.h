@@ -51,6 +51,7 @@ struct ProlongTable {
     float *row_hi_f = nullptr, *row_lo_f = nullptr, *col_hi_f = nullptr, *col_lo_f = nullptr;  // rounded to fp32
     double c_dx = 0.0;
     bool fusable = false;  // every fine index owned, owners advance by <= 1 per fine index
+    bool fusable4 = false; // ... and 4 aligned fine columns span at most 3 coarse cells (4 columns per lane, fp32)
 };
 
 // a window of grid rows held in a local array: rows [base, base+rows) of the global grid

@@ -25,6 +25,7 @@ void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *
         tb.p_clo = pt->col_lo_f;
         tb.c_dx = (float)pt->c_dx;
         tb.c_dx_rcp = 1.0f / tb.c_dx;  // IEEE fp32 division on the host: correctly rounded
+        tb.p_cols4_ok = pt->fusable4;
     }
     if (Fc) {
         tb.r_inv = rt->inv;

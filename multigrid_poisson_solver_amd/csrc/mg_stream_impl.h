@@ -66,6 +66,7 @@ struct StreamTables {
     const int *p_orow = nullptr, *p_ocol = nullptr;
     const real_t *p_rhi = nullptr, *p_rlo = nullptr, *p_chi = nullptr, *p_clo = nullptr;
     real_t c_dx = 0, c_dx_rcp = 0;
+    bool p_cols4_ok = false;   // ProlongTable::fusable4
     const int *r_inv = nullptr;
     const real_t *r_w = nullptr, *r_wf = nullptr;
 };
@@ -78,6 +79,7 @@ constexpr int MAX_S = 4;
 enum InMode { IN_LOAD = 0, IN_ZERO = 1, IN_PROLONG = 2 };
 
 typedef real_t real2_t __attribute__((ext_vector_type(2)));
+typedef real_t real4_t __attribute__((ext_vector_type(4)));
 
 struct StreamParams {
     int N;
@@ -89,6 +91,7 @@ struct StreamParams {
     int d_sign;
     double *part;       // nullptr: no error norm; else one partial per wave
     long long *trace;   // MG_STREAM_TRACE builds only
+    int cols4;          // fp32 fields: 4 columns (16 B) per lane instead of 2
     int rows_per_chunk;
     int groups;         // workgroups per chunk row
     int n_blocks;       // chunks * groups
@@ -185,6 +188,12 @@ __device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ row, un
         const real2_t t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(a)) : *reinterpret_cast<const real2_t *>(a);
         r.v[0] = t.x;
         r.v[1] = t.y;
+    } else if constexpr (COLS == 4) {
+        const real4_t t = NT ? __builtin_nontemporal_load(reinterpret_cast<const real4_t *>(a)) : *reinterpret_cast<const real4_t *>(a);
+        r.v[0] = t.x;
+        r.v[1] = t.y;
+        r.v[2] = t.z;
+        r.v[3] = t.w;
     } else {
         r.v[0] = *reinterpret_cast<const real_t *>(a);
     }
@@ -204,6 +213,14 @@ __device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col
         t.y = r.v[1];
         if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real2_t *>(a));
         else *reinterpret_cast<real2_t *>(a) = t;
+    } else if constexpr (COLS == 4) {
+        real4_t t;
+        t.x = r.v[0];
+        t.y = r.v[1];
+        t.z = r.v[2];
+        t.w = r.v[3];
+        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real4_t *>(a));
+        else *reinterpret_cast<real4_t *>(a) = t;
     } else {
         *reinterpret_cast<real_t *>(a) = r.v[0];
     }
@@ -212,9 +229,10 @@ __device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col
 // halo columns per side: level S must be valid one column beyond the owned strip for the
 // residual stage, two for the fused restriction (it reads the residual one column and one
 // row beyond the owned tile); rounded up to even so strips stay 16 B aligned
-template <int S, bool RESTRICT>
+template <int S, bool RESTRICT, int COLS = 2>
 struct Halo {
-    static constexpr int value = (S + (RESTRICT ? 2 : 1) + 1) & ~1;
+    static constexpr int A = COLS > 2 ? COLS : 2;  // strips start on a multiple of the lane's column count (16 B loads)
+    static constexpr int value = (S + (RESTRICT ? 2 : 1) + A - 1) / A * A;
 };
 
 // `zero ? 0 : v` for a lane constant v whose low 32 bits are zero (0.25, +-1.0, 0.0) and a wave-uniform
@@ -228,22 +246,24 @@ __device__ __forceinline__ float uniform_or_zero(bool zero, float v) { return ze
 __device__ __forceinline__ double fused_mul_add(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fused_mul_add(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// three consecutive coarse values of one coarse row, starting at this lane's base column
-struct Coarse3 {
-    real_t v[3];
+// NCV consecutive coarse values of one coarse row, starting at this lane's base column (COLS/2 + 2: the COLS fine
+// columns of a lane lie in at most COLS/2 + 1 coarse cells)
+template <int NCV>
+struct CoarseV {
+    real_t v[NCV];
 };
 // unconditional like load_row: rows fetched ahead of need may lie outside the local window (clamped)
 // and columns past the grid are clamped (never consumed); col[] are the lane's three clamped columns
-__device__ __forceinline__ Coarse3 load_coarse(const real_t *__restrict__ coarse, int Nc, int base, int rows, int row,
-                                               const unsigned (&col)[3])
+template <int NCV>
+__device__ __forceinline__ CoarseV<NCV> load_coarse(const real_t *__restrict__ coarse, int Nc, int base, int rows, int row,
+                                                    const unsigned (&col)[NCV])
 {
-    Coarse3 c;
+    CoarseV<NCV> c;
     int r = row - base;
     r = r < 0 ? 0 : (r < rows - 1 ? r : rows - 1);
     const char *b = reinterpret_cast<const char *>(coarse + (size_t)r * Nc);
-    c.v[0] = *reinterpret_cast<const real_t *>(b + col[0]);   // col[] in bytes
-    c.v[1] = *reinterpret_cast<const real_t *>(b + col[1]);
-    c.v[2] = *reinterpret_cast<const real_t *>(b + col[2]);
+#pragma unroll
+    for (int q = 0; q < NCV; ++q) c.v[q] = *reinterpret_cast<const real_t *>(b + col[q]);   // col[] in bytes
     return c;
 }
 
@@ -262,23 +282,26 @@ __device__ __forceinline__ double hi_bits_and(double v, int mask) { return __hil
 __device__ __forceinline__ float hi_bits_and(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
 
 // the same with the local (already clamped) row index of the coarse array
-__device__ __forceinline__ Coarse3 load_coarse_local(const real_t *__restrict__ coarse, int Nc, int local_row, const unsigned (&col)[3])
+template <int NCV>
+__device__ __forceinline__ CoarseV<NCV> load_coarse_local(const real_t *__restrict__ coarse, int Nc, int local_row, const unsigned (&col)[NCV])
 {
-    Coarse3 c;
+    CoarseV<NCV> c;
     const char *b = reinterpret_cast<const char *>(coarse + (size_t)local_row * Nc);
-    c.v[0] = *reinterpret_cast<const real_t *>(b + col[0]);
-    c.v[1] = *reinterpret_cast<const real_t *>(b + col[1]);
-    c.v[2] = *reinterpret_cast<const real_t *>(b + col[2]);
+#pragma unroll
+    for (int q = 0; q < NCV; ++q) c.v[q] = *reinterpret_cast<const real_t *>(b + col[q]);
     return c;
 }
 
 template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
-    static_assert(COLS == 2 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
+    static_assert(COLS == 2 || COLS == 4 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
+    static_assert(COLS != 4 || sizeof(real_t) == 4, "4 columns per lane = one 16-byte access: fp32 fields only");
+    constexpr int NCV = COLS / 2 + 2;  // coarse values a lane needs of one coarse row
+    constexpr int NS = COLS >= 2 ? COLS / 2 : 1;  // coarse columns a lane can produce (one per column pair)
     static_assert(PF + S + 2 <= 8 && PF < 4, "the F ring has 8 slots, the U ring 4");
     constexpr int W = 64 * COLS;
-    constexpr int H = Halo<S, RESTRICT>::value;
+    constexpr int H = Halo<S, RESTRICT, COLS>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
 
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
@@ -342,52 +365,74 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const unsigned row_bytes = (unsigned)N * (unsigned)sizeof(real_t);
 
     // ---- fused prolongation input: per-lane column tables, horizontal interpolants of two coarse rows
-    unsigned pc_col[3] = {0u, 0u, 0u};  // the lane's three coarse columns (clamped), as byte offsets
-    bool pc_second_shift = false;       // second fine column belongs to the next coarse cell
-    real_t pc_hi[2] = {0.0, 0.0}, pc_lo[2] = {0.0, 0.0};
+    unsigned pc_col[NCV];               // the lane's coarse columns (clamped), as byte offsets
+    int pc_cell[COLS];                  // coarse cell of fine column j, relative to the lane's first cell
+    real_t pc_hi[COLS], pc_lo[COLS];
     // hA[j] / hB[j]: doProlongation's (c1*(c2x-f_x) + c2*(f_x-c1x)) resp. (c3*... + c4*...) of :700 for coarse
     // rows c_row / c_row + 1 at this lane's fine column j.  They change only when the owner row advances
     // (every other fine row), not with every fine row.
-    real_t hA[2] = {0.0, 0.0}, hB[2] = {0.0, 0.0};
+    real_t hA[COLS], hB[COLS];
+#pragma unroll
+    for (int q = 0; q < NCV; ++q) pc_col[q] = 0u;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        pc_cell[j] = 0;
+        pc_hi[j] = pc_lo[j] = hA[j] = hB[j] = real_t(0.0);
+    }
     int c_row = -0x40000000;            // coarse row behind hA (wave-uniform); hB belongs to c_row + 1
     if constexpr (IN == IN_PROLONG) {
         if (lane_loads) {
             const int pc_base = p.p_ocol[xl];
-            pc_second_shift = p.p_ocol[xl + 1] != pc_base;
-            pc_hi[0] = p.p_chi[xl];
-            pc_lo[0] = p.p_clo[xl];
-            pc_hi[1] = p.p_chi[xl + 1];
-            pc_lo[1] = p.p_clo[xl + 1];
             const int last = p.Nc - 1;
-            pc_col[0] = (unsigned)pc_base * (unsigned)sizeof(real_t);
-            pc_col[1] = (unsigned)(pc_base + 1 < last ? pc_base + 1 : last) * (unsigned)sizeof(real_t);
-            pc_col[2] = (unsigned)(pc_base + 2 < last ? pc_base + 2 : last) * (unsigned)sizeof(real_t);
+#pragma unroll
+            for (int j = 0; j < COLS; ++j) {
+                pc_cell[j] = p.p_ocol[xl + j] - pc_base;
+                pc_hi[j] = p.p_chi[xl + j];
+                pc_lo[j] = p.p_clo[xl + j];
+            }
+#pragma unroll
+            for (int q = 0; q < NCV; ++q) pc_col[q] = (unsigned)(pc_base + q < last ? pc_base + q : last) * (unsigned)sizeof(real_t);
         }
     }
-    auto interpolate = [&](const Coarse3 &c, real_t (&h)[2]) {
+    auto interpolate = [&](const CoarseV<NCV> &c, real_t (&h)[COLS]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool sh = j == 1 && pc_second_shift;
-            const real_t ca = sh ? c.v[1] : c.v[0], cb = sh ? c.v[2] : c.v[1];
+        for (int j = 0; j < COLS; ++j) {
+            real_t ca = c.v[0], cb = c.v[1];
+#pragma unroll
+            for (int q = 1; q + 1 < NCV; ++q) {  // (host-checked: the cell index stays below NCV - 1)
+                const bool here = pc_cell[j] == q;
+                ca = here ? c.v[q] : ca;
+                cb = here ? c.v[q + 1] : cb;
+            }
             h[j] = ca * pc_hi[j] + cb * pc_lo[j];
         }
     };
 
     // ---- fused restriction output: which coarse column this lane produces -------------
-    int rc_col = -1;          // coarse column (interior) or -1
-    bool rc_shift = false;    // its lower-left fine sample is this lane's SECOND column
-    real_t rw_a = 0.0, rw_b = 0.0;
+    // (one slot per column pair of the lane: lo[] advances by >= 2, so a pair holds at most one sample)
+    int rc_col[NS];           // coarse column (interior) or -1
+    bool rc_shift[NS];        // its lower-left fine sample is the pair's SECOND column
+    real_t rw_a[NS], rw_b[NS];
     Row<COLS> d_prev;         // signed residual of the previous row
 #pragma unroll
     for (int j = 0; j < COLS; ++j) d_prev.v[j] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        rc_col[q] = -1;
+        rc_shift[q] = false;
+        rw_a[q] = rw_b[q] = real_t(0.0);
+    }
     if constexpr (RESTRICT) {
         if (lane_owns) {
-            const int ca = p.r_inv[xl], cb = p.r_inv[xl + 1];
-            rc_col = ca >= 0 ? ca : cb;
-            rc_shift = ca < 0 && cb >= 0;
-            if (rc_col >= 0) {
-                rw_a = p.r_w[rc_col];
-                rw_b = real_t(1.0) - rw_a;  // src/MG_solver_CPU.cpp:665
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const int ca = p.r_inv[xl + 2 * q], cb = p.r_inv[xl + 2 * q + 1];
+                rc_col[q] = ca >= 0 ? ca : cb;
+                rc_shift[q] = ca < 0 && cb >= 0;
+                if (rc_col[q] >= 0) {
+                    rw_a[q] = p.r_w[rc_col[q]];
+                    rw_b[q] = real_t(1.0) - rw_a[q];  // src/MG_solver_CPU.cpp:665
+                }
             }
         }
     }
@@ -400,7 +445,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         for (int edge = 0; edge < 2; ++edge) {
             if (edge == 0 ? (y0 != 0) : (y1 != N)) continue;
             real_t *row = p.Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
-            if (rc_col >= 0) row[rc_col] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                if (rc_col[q] >= 0) row[rc_col[q]] = 0.0;
             if (first_col_lane) row[0] = 0.0;
             if (last_col_lane) row[p.M - 1] = 0.0;
         }
@@ -476,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
     constexpr int NB = 8, NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
     Row<COLS> fr[NB], pu[NU];
-    Coarse3 pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
+    CoarseV<NCV> pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
     int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
 #pragma unroll
     for (int k = 0; k < NB; ++k)
@@ -486,7 +533,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     for (int k = 0; k < NU; ++k) {
 #pragma unroll
         for (int j = 0; j < COLS; ++j) pu[k].v[j] = 0.0;
-        pc[k].v[0] = pc[k].v[1] = pc[k].v[2] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NCV; ++q) pc[k].v[q] = 0.0;
         q_own[k] = -1;
     }
 
@@ -508,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             // the UPPER coarse row of this input row travels with it, so every vector load of the loop is issued at
             // a fixed place PF steps before its use
             q_own[u8 % NU] = lane_value(tb_own, ld_t & 63);
-            pc[u8 % NU] = load_coarse_local(p.coarse, p.Nc, lane_value(tb_crow, ld_t & 63), pc_col);
+            pc[u8 % NU] = load_coarse_local<NCV>(p.coarse, p.Nc, lane_value(tb_crow, ld_t & 63), pc_col);
         }
         ++ld_t;
         // the clamped row moves on only inside the window: av_lo < y_first + ld_t < av_hi
@@ -522,7 +570,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         const int ys = y_first > av_lo ? y_first : av_lo;
         if (ys < av_hi && ys < y_end) {
             const int i0 = table_i(p.p_orow, ys);
-            const Coarse3 c0 = load_coarse(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
+            const CoarseV<NCV> c0 = load_coarse<NCV>(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
             interpolate(c0, hB);
             c_row = i0 - 1;
         }
@@ -578,7 +626,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 nw = pu[k % NU];
             }
             const int own_i = q_own[k % NU];
-            const Coarse3 own_up = pc[k % NU];
+            const CoarseV<NCV> own_up = pc[k % NU];
             if constexpr (IN == IN_PROLONG) {
                 // the prefetch below reads the owner of row t + PF: from step 64 m - PF on that is the next block
                 if (k == NB - PF && (t0 & 63) == 56) {
@@ -594,7 +642,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 if (own_i >= 0) {
                     if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) hA[j] = hB[j];
+                        for (int j = 0; j < COLS; ++j) hA[j] = hB[j];
                         c_row = own_i;
                         interpolate(own_up, hB);  // row own_i + 1, loaded PF iterations ago
                     }
@@ -644,8 +692,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                         // mixed precision: the last node of a cycle hands its result over in fp64 (exact
                         // widening) instead of leaving it to a separate conversion pass
                         double *w = reinterpret_cast<double *>(reinterpret_cast<char *>(p.out_wide) + 2 * st_off + 2u * col_st);  // 8 B per element here
+                        typedef double wide2_t __attribute__((ext_vector_type(2)));
+                        if constexpr (COLS % 2 == 0) {  // 16-byte stores (column pairs are 16-byte aligned in the fp64 array)
 #pragma unroll
-                        for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
+                            for (int j = 0; j < COLS; j += 2) {
+                                wide2_t t;
+                                t.x = (double)nw.v[j];
+                                t.y = (double)nw.v[j + 1];
+                                // (4 columns per lane: the two 16-byte halves of a lane's 32 bytes come from two instructions, each
+                                // strided by 32 B; a streaming store would write the half lines out one by one: let L2 merge them)
+                                if (COLS == 2) __builtin_nontemporal_store(t, reinterpret_cast<wide2_t *>(w + j));
+                                else *reinterpret_cast<wide2_t *>(w + j) = t;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
+                        }
                     } else {
                         store_row<COLS>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.out) + st_off), col_st, nw, nt_stores);
                     }
@@ -690,14 +752,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                         const real_t wc = lane_value(tb_rw, t & 63), wd = real_t(1.0) - wc;  // c, d of :664-666
                         const real_t p_up = from_lane_above(d_prev.v[0]);
                         const real_t q_up = from_lane_above(d.v[0]);
-                        const real_t u0 = rc_shift ? d_prev.v[1] : d_prev.v[0];
-                        const real_t u1 = rc_shift ? p_up : d_prev.v[1];
-                        const real_t u2 = rc_shift ? d.v[1] : d.v[0];
-                        const real_t u3 = rc_shift ? q_up : d.v[1];
-                        // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
-                        const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
                         real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
-                        if (rc_col >= 0) crow[rc_col] = vc;
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) {
+                            // the column after the pair: the lane's next pair, or the next lane's first column
+                            const real_t p_next = q + 1 < NS ? d_prev.v[q + 1 < NS ? 2 * q + 2 : 0] : p_up;
+                            const real_t q_next = q + 1 < NS ? d.v[q + 1 < NS ? 2 * q + 2 : 0] : q_up;
+                            const real_t u0 = rc_shift[q] ? d_prev.v[2 * q + 1] : d_prev.v[2 * q];
+                            const real_t u1 = rc_shift[q] ? p_next : d_prev.v[2 * q + 1];
+                            const real_t u2 = rc_shift[q] ? d.v[2 * q + 1] : d.v[2 * q];
+                            const real_t u3 = rc_shift[q] ? q_next : d.v[2 * q + 1];
+                            // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
+                            const real_t vc = rw_b[q] * wd * u0 + rw_a[q] * wd * u1 + wc * rw_b[q] * u2 + rw_a[q] * wc * u3;
+                            if (rc_col[q] >= 0) crow[rc_col[q]] = vc;
+                        }
                         if (first_col_lane) crow[0] = 0.0;
                         if (last_col_lane) crow[p.M - 1] = 0.0;
                     }
@@ -750,7 +818,7 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int N = p.N;
     const int own = p.own_y1 - p.own_y0;  // rows this launch updates (N on a single GPU)
     if (own <= 0) return;
-    constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT>::value;
+    constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT, COLS>::value;
     const int strips = (N + OW - 1) / OW;
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     static const int resident_pct = [] { const char *e = getenv("MG_RESIDENT_PCT"); return e ? atoi(e) : 100; }();
@@ -829,6 +897,22 @@ template <int S, int PF>
 void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
 {
     const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
+    if constexpr (sizeof(real_t) == 4) {
+        // fp32 fields, 16 B per lane: the same kernel with 4 columns per lane (8 B per lane leaves it bound by its
+        // instruction stream at half the bytes per instruction of the fp64 build)
+        if (p.cols4) {
+            if (restrict_out) {
+                if (zero) launch_k<S, 4, IN_ZERO, true, PF>(s, p, err_out);
+                else launch_k<S, 4, IN_LOAD, true, PF>(s, p, err_out);
+            } else if (prolong_in) {
+                launch_k<S, 4, IN_PROLONG, false, PF>(s, p, err_out);
+            } else {
+                if (zero) launch_k<S, 4, IN_ZERO, false, PF>(s, p, err_out);
+                else launch_k<S, 4, IN_LOAD, false, PF>(s, p, err_out);
+            }
+            return;
+        }
+    }
     if (p.N % 2 != 0) {  // 8 B lanes: odd row pitch; the fused transfer stages are not built for it
         if (zero) launch_k<S, 1, IN_ZERO, false, PF>(s, p, err_out);
         else launch_k<S, 1, IN_LOAD, false, PF>(s, p, err_out);
@@ -889,6 +973,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.norm_y0 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_lo : p.own_y0;
     p.norm_y1 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_hi : p.own_y1;
     p.raw_norm = fine_w ? 1 : 0;
+    static const int cols4_min = [] { const char *e = getenv("MG_F32_COLS4_MIN_N"); return e ? atoi(e) : 8192; }();  // (measured: a gain only where the launch is bandwidth-bound, N >= 8192)
+    p.cols4 = (sizeof(real_t) == 4 && N % 4 == 0 && N >= cols4_min && (!coarse || tb.p_cols4_ok)) ? 1 : 0;
     static const int nt_min = [] { const char *e = getenv("MG_NT_MIN_N"); return e ? atoi(e) : 2048; }();
     p.nt_min_n = nt_min;
     if (coarse) {

@@ -163,6 +163,11 @@ const ProlongTable &prolong_table(int N, int M)
         t.col_lo_f = upload(clf);
         t.c_dx = 1.0 / (double)(N - 1);
         t.fusable = fusable;
+        // four consecutive fine columns starting on a multiple of 4 span at most three coarse cells: what the
+        // 4-columns-per-lane form of the fused prolongation (fp32 fields) holds per lane
+        t.fusable4 = fusable && M % 4 == 0;
+        for (int k = 0; k + 3 < M && t.fusable4; k += 4)
+            if (ocol[k + 3] - ocol[k] > 2) t.fusable4 = false;
     }
     return c.ptab.emplace(key, t).first->second;
 }

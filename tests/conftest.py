@@ -20,6 +20,9 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 # slab plans fill freshly allocated level arrays with NaN: a halo row that nobody wrote (no exchange, no
 # redundant computation) then shows up in the compared result instead of passing on stale data
 os.environ.setdefault("MG_SLAB_POISON", "1")
+# the 4-columns-per-lane form of the fp32 kernels is the product's choice from N = 8192 on (where it pays); the tests
+# take it from N = 1024 on, so that the numpy restatement can check it bit for bit at sizes it finishes in seconds
+os.environ.setdefault("MG_F32_COLS4_MIN_N", "1024")
 
 
 def pytest_configure(config):

@@ -15,7 +15,7 @@ def bits32(a, b):
     return a.shape == b.shape and np.array_equal((a + np.float32(0)).view(np.uint32), (b + np.float32(0)).view(np.uint32))
 
 
-@pytest.mark.parametrize("N", [8, 16, 64, 256, 1024])
+@pytest.mark.parametrize("N", [8, 16, 64, 256, 1024, 1448, 2048])
 @pytest.mark.parametrize("step", [1, 3, 4])
 def test_fused_nodes_fp32_vs_numpy(mg, N, step):
     M = N // 2
