@@ -124,6 +124,8 @@ def compulsory_bytes(kernel_family, N):
     coarse F out (U is zero-filled in registers); `1` node: U, F, coarse U in, U out; plain
     S-sweep launch: U, F in, U out.  2 B/pt of table/halo overhead are not counted."""
     n = float(N) * N
+    if "widen" in kernel_family:   # fp32 `1` node that stores its result in fp64: counted in fp64-equivalent units (x 0.5 later)
+        return 24.0 * n + 8.0 * (N // 2) ** 2 + 8.0 * n
     if "restrict" in kernel_family:
         return 16.0 * n + 8.0 * (N // 2) ** 2
     if "prolong" in kernel_family:
