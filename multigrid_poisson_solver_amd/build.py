@@ -61,14 +61,19 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-result"]
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-result",
+              # the same bytes wherever the tree is checked out (__FILE__ in the error macros): bench.py ties the
+              # committed rocprofv3 traffic record to the sha of this library
+              f"-ffile-prefix-map={ROOT}=."]
     common += os.environ.get("MG_EXTRA_CXXFLAGS", "").split()
     if force or _stale(LIB, deps):
         objs = []
         for s in srcs:
             o = os.path.join(PKG, "lib", os.path.basename(s) + ".o")
             if force or _stale(o, deps if s.endswith(".hip") else [s] + deps[len(srcs):]):
-                cmd = common + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+                # -cuid: hipcc derives the compilation-unit id (part of internal symbol names) from the source PATH by
+                # default; a fixed one per file keeps the library's bytes independent of where the tree lies
+                cmd = common + (["-x", "hip"] if s.endswith(".hip") else []) + ["-cuid=mg_" + os.path.basename(s).replace(".", "_"), "-c", s, "-o", o]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True)
