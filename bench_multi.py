@@ -157,6 +157,10 @@ def run(args, rank, world, local_rank):
             uid = [mg.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             mg.comm_init(rank, world, uid[0])
+            # sanity gate before anything is timed: the calls the slab driver makes (grouped send/recv on a second
+            # stream, all-gather over all ranks) must deliver their bytes
+            if mg.lib().mg_comm_selftest(1 << 16) != 0:
+                raise SystemExit(f"rank {rank}: RCCL self-test failed: {mg.lib().mg_last_error_string()}")
 
     tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
     N_weak = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n

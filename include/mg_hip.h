@@ -251,6 +251,9 @@ typedef struct mg_host_transport {
     int (*allgather)(void *user, const double *send, double *recv, size_t count_per_rank);
 } mg_host_transport;
 int  mg_comm_init_host(int rank, int nranks, const mg_host_transport *transport);
+/* exercises the RCCL calls of the slab driver (grouped send/recv on a second stream ordered by events, all-gather)
+ * against this rank itself and checks the bytes; 0 = ok.  Runs with a 1-rank communicator on a one-GPU box. */
+int  mg_comm_selftest(size_t n_doubles);
 void mg_comm_finalize(void);
 int  mg_comm_rank(void);
 int  mg_comm_size(void);

@@ -80,7 +80,7 @@ ABI = {
     "mg_print2File": (_i, [_i, _vp, C.c_char_p]),
     "mg_comm_unique_id_bytes": (_i, []), "mg_comm_get_unique_id": (_i, [_vp]),
     "mg_comm_init_host": (_i, [_i, _i, _vp]),
-    "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_rank": (_i, []),
+    "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_selftest": (_i, [_sz]), "mg_comm_rank": (_i, []),
     "mg_comm_size": (_i, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),

@@ -40,15 +40,16 @@ inline hipStream_t cur_stream() { return g_stream ? g_stream : ctx().stream; }
 struct Rccl {
     void *handle = nullptr;
     bool tried = false;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // (pointer types taken from the declarations of <rccl/rccl.h>: a signature cannot drift from the header)
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclAllGather) AllGather = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
     std::string where;
 } g_rccl;
 
@@ -279,6 +280,56 @@ void mg_comm_finalize(void)
     }
     g_rank = 0;
     g_nranks = 1;
+}
+
+// Exercises the RCCL entry points the slab driver uses -- a grouped send/recv pair (to this rank itself) on a
+// second stream ordered by events against the engine's stream, and an all-gather -- and checks the bytes that
+// arrived.  Works with a 1-rank communicator, i.e. on a one-GPU box.  Returns 0 when everything matched.
+int mg_comm_selftest(size_t n_doubles)
+{
+    if (!require_ready("mg_comm_selftest")) return 1;
+    if (!g_comm) {
+        fail(MG_ERR_COMM, "mg_comm_selftest: no RCCL communicator (mg_comm_init)");
+        return 1;
+    }
+    Context &c = ctx();
+    const size_t n = n_doubles ? n_doubles : 4096;
+    double *a = (double *)c.pool.get(n * sizeof(double)), *b = (double *)c.pool.get(n * sizeof(double));
+    double *g = (double *)c.pool.get(n * (size_t)g_nranks * sizeof(double));
+    if (!a || !b || !g) return 1;
+    k::fill_uniform(c.stream, a, n, 0x5e1f7e57ull + (uint64_t)g_rank);
+    (void)hipMemsetAsync(b, 0, n * sizeof(double), c.stream);
+    hipStream_t s2 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 1;
+    if (MG_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) && MG_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming)) &&
+        MG_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming))) {
+        (void)hipEventRecord(e0, c.stream);
+        (void)hipStreamWaitEvent(s2, e0, 0);
+        comm_set_stream(s2);
+        comm_group_begin();
+        comm_send(a, n * sizeof(double), g_rank);
+        comm_recv(b, n * sizeof(double), g_rank);
+        comm_group_end();
+        comm_set_stream(nullptr);
+        (void)hipEventRecord(e1, s2);
+        (void)hipStreamWaitEvent(c.stream, e1, 0);
+        comm_allgather(b, g, n);
+        std::vector<double> ha(n), hb(n), hg(n * (size_t)g_nranks);
+        mg_download(ha.data(), a, n);
+        mg_download(hb.data(), b, n);
+        mg_download(hg.data(), g, hg.size());
+        rc = (memcmp(ha.data(), hb.data(), n * sizeof(double)) == 0 &&
+              memcmp(ha.data(), hg.data() + (size_t)g_rank * n, n * sizeof(double)) == 0 && c.last_error == 0)
+                 ? 0 : 2;
+    }
+    if (s2) (void)hipStreamDestroy(s2);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    c.pool.put(a);
+    c.pool.put(b);
+    c.pool.put(g);
+    return rc;
 }
 
 int mg_comm_rank(void) { return g_rank; }

@@ -118,6 +118,11 @@ def test_rccl_communicator_single_rank(mg):
     assert len(uid) == mg.lib().mg_comm_unique_id_bytes()
     mg.comm_init(0, 1, uid)
     assert mg.lib().mg_comm_rank() == 0 and mg.lib().mg_comm_size() == 1
+    # the calls the slab driver makes, through the lazily resolved entry points: a grouped ncclSend/ncclRecv pair
+    # (to this rank itself) on a second stream ordered by events, then ncclAllGather; the bytes must arrive
+    for n in (1, 4096, 1 << 20):
+        assert mg.lib().mg_comm_selftest(n) == 0
+        assert mg.lib().mg_last_error() == 0, mg.lib().mg_last_error_string()
     mg.lib().mg_comm_finalize()
 
 
