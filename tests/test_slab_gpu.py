@@ -100,6 +100,39 @@ def test_virtual_slabs_match_single_gpu_driver_at_full_size(mg, tmp_path, N, mix
     plan.close(); single.close()
 
 
+def test_config4_size_vs_oracle(mg, oracle, tmp_path):
+    """BASELINE.json configs[3] at full size against the ORACLE itself (not only against the single-GPU driver): the
+    V(3,3)-cycle at N = 16384^2, single-GPU fused driver and 8 row slabs (communication-avoiding schedule, NaN-poisoned
+    slab arrays), final U through the 128-bit checksum, every smoothing error, the analytic error."""
+    import ctypes as C
+    import _synth
+    N = 16384
+    path = str(tmp_path / f"V{N}.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path, want_report=False)
+    assert want["status"] == 0
+    want_sum = _synth.checksum(want["U"])
+    want_err, want_rec = want["mg_error"], want["records"]
+    del want
+    single = mg.CyclePlan(path, fused=True, report=False)
+    got = single.execute()
+    out = (C.c_uint64 * 2)()
+    mg.lib().mg_checksum(got["U_ptr"], N * N, out)
+    assert (int(out[0]), int(out[1])) == want_sum, "single-GPU driver at 16384^2 differs from the oracle"
+    assert got["mg_error"] == pytest.approx(want_err, rel=1e-10)
+    single.close()
+    mg.lib().mg_pool_trim()
+    plan = mg.SlabPlan(path, 8, -1, 1024)
+    res = plan.execute()
+    assert res["status"] == 0
+    assert _synth.checksum(plan.gather_U(N)) == want_sum, "8 row slabs at 16384^2 differ from the oracle"
+    assert res["mg_error"] == pytest.approx(want_err, rel=1e-10)
+    for g, w in zip(res["records"], want_rec):
+        assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    plan.close()
+    mg.lib().mg_pool_trim()
+
+
 def test_slab_mode_refuses_what_it_does_not_implement(mg, tmp_path):
     trig = tmp_path / "trigger.txt"
     trig.write_text("1.0 0.0 0.0\n-1 1\n256 8\n-1\n-1\n0\n0.0000001 1\n1\n1\n2")
