@@ -153,25 +153,32 @@ def test_weak_scaling_grid_sizes():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_bench_line.json is what bench.py printed on the MI355X: the keys the driver and the judge
-    read must be there, the roofline must be priced consistently, the traffic file must cover the dominant kernel."""
+    """profiles/r02_bench_line.json is what bench.py printed on the MI355X: the keys the driver and the judge read must
+    be there; `roofline.frac` is PHYSICAL (compulsory bytes / time / peak, below 1), the per-sweep accounting of SURVEY 8d
+    sits beside it as `algorithmic_equiv`; the counter-measured traffic is tied to the profiled library's sha."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01_bench_line.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "strong_scaling", "single_sweep_roofline"):
         assert k in d, k
     assert d["unit"] == "MLUPS" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == 1
-    assert "workload" in d["config"] and "8192" in d["config"]["workload"]
+    assert "workload" in d["config"] and "8192" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["traffic"] is not None and 0.9 < r["traffic"] / r["hbm"]["compulsory_bytes"] < 1.2   # counters vs compulsory bytes
-    assert 0.4 < r["hbm"]["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.4 < r["frac"] < 0.8
+    assert abs(r["achieved"] - r["compulsory_bytes"] / (r["avg_ms"] * 1e-3) / 1e9) < 1.0
+    assert r["algorithmic_equiv"]["GBs"] > r["peak"]                    # S sweeps per pass: a saving, not a bandwidth
+    t = r["traffic"]
+    assert t is not None and len(t["lib_sha"]) == 16 and 0.95 < t["bytes"] / r["compulsory_bytes"] < 1.15   # counters vs compulsory bytes
+    assert set(d["single_sweep_roofline"]) == {"k_jacobi_pair", "k_jacobi_stream_S1"}
     lups = 6 * sum((8192 >> l) ** 2 for l in range(10))
     assert abs(d["value"] - lups / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
+    s = d["strong_scaling"]
+    assert s["N"] == 16384 and s["n_gpus"] == 1 and s["value"] > 0
     c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c and c["value"] > 0
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c and c["value"] > 0 and c["reps"] == 3
+    assert {"makefile_flags", "one_thread"} <= set(c["variants"])
 
 
 def test_exp_table_and_algorithm_reproduce_this_libm():
