@@ -262,7 +262,6 @@ struct TailArgsT {
     const T *p_rhi[TAIL_MAX_LEVELS], *p_rlo[TAIL_MAX_LEVELS], *p_chi[TAIL_MAX_LEVELS], *p_clo[TAIL_MAX_LEVELS];
     T c_dx[TAIL_MAX_LEVELS];
     int tab_real0, tab_int0;  // where the staged tables start in LDS (set by the launcher)
-    int gs_ring0;             // pipelined exact solver: ring of iterates + flags, offset in doubles (-1: no room)
     long long *trace;         // diagnostics (MG_TAIL_TRACE): 100 MHz timestamps at start, after staging, after each node
     const T *F_top;
     T *U_top;

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
 
 // LDS layout: level arrays | (fp32 fields) fp64 scratch of the block exact solver | real tables | int tables
 struct TailLayout {
-    int tab_real0, tab_int0, gs_ring0;
+    int tab_real0, tab_int0;
     size_t bytes;
 };
 inline TailLayout tail_layout(const TailArgsT<real_t> &a)
@@ -668,7 +668,6 @@ inline TailLayout tail_layout(const TailArgsT<real_t> &a)
     bytes += (n_real * sizeof(real_t) + 7) / 8 * 8;
     L.tab_int0 = (int)(bytes / sizeof(int));
     bytes += n_int * sizeof(int);
-    L.gs_ring0 = -1;
     L.bytes = bytes;
     return L;
 }
@@ -685,7 +684,6 @@ inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
     TailArgsT<real_t> b = a;
     b.tab_real0 = L.tab_real0;
     b.tab_int0 = L.tab_int0;
-    b.gs_ring0 = L.gs_ring0;
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(TAIL_THREADS), L.bytes, s, b);
 }
 
