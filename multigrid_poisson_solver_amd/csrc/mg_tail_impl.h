@@ -321,12 +321,12 @@ __device__ void gauss_seidel_wave(int N, double h2, double inv, int src, int F, 
 //     row supply the rim zeros).  a, d are the red points of a block, b, c the black ones -- the same in every lane,
 //     so there is no per-lane colour select either;
 //   * the reference tests `err > target_error` after every sweep (:996), err = sum|r|/(N-2)^2 (:1051-1059).  The
-//     shifted values the NEXT red pass needs are exactly the neighbours of the red points of this iterate, so the
-//     residuals of the two red points of every lane cost 12 more flops; their sum is a LOWER bound of the norm's
-//     sum.  While some lane's bound exceeds twice the target (the factor 2 swallows the rounding of the real
-//     summation many times over) the answer of the full test is known to be "go on" and the full norm -- the black
-//     residuals and the reduction -- is skipped; near convergence (the last ~10 iterations) the full norm runs
-//     every iteration.  The iterates, the stopping iteration and the result are those of the reference.
+//     red half of the NEXT sweep is computed first and held aside: its step a' - a IS the residual of that red point
+//     in this iterate (times h^2/4, up to a rounding bounded in the code below), so one subtraction and one compare
+//     per red point give a LOWER bound of the norm's sum.  While some lane's bound exceeds twice the target the
+//     answer of the full test is known to be "go on" and the full norm -- four residuals and the reduction -- is
+//     skipped; near convergence (the last ~10 iterations) the full norm runs every iteration.  The iterates, the
+//     stopping iteration and the result are those of the reference.
 // (A version that published every iterate to the other 15 waves for judging was measured slower than the lone-wave
 // solver it replaced: every LDS operation costs the latency-critical wave 40-100 cycles.)
 template <int CTRL>
@@ -355,49 +355,117 @@ __device__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F
             fc = (double)FF(p00 + N);
             fd = (double)FF(p00 + N + 1);
         }
-        const double ha = h2 * fa, hb = h2 * fb, hc = h2 * fc, hd = h2 * fd;
         const double q = active ? 0.25 : 0.0;       // lanes without a block stay zero: they ARE the rim
+        // 0.25*(s - h^2 F) as ONE fma, fma(0.25, s, -(0.25*h^2 F)): scaling by a power of two commutes with the
+        // rounding (below the denormal range nothing here lives), so the bits are those of :1020's expression
+        const double qa = q * (h2 * fa), qb = q * (h2 * fb), qc = q * (h2 * fc), qd = q * (h2 * fd);
         const double keep = active ? 1.0 : 0.0;
         const double denom = (double)((N - 2) * (N - 2));
         // `sum/denom > tol` without the division wherever rounding cannot matter (see gsw::solve)
-        const double thr = tol * denom, thr_hi = thr * (1.0 + 0x1p-48), thr_lo = thr * (1.0 - 0x1p-48), thr_sure = 2.0 * thr;
-        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;  // memset(U, 0)  :993
-        double b_w = 0.0, c_s = 0.0, c_e = 0.0, b_n = 0.0;  // lane-1's b, lane-4's c, lane+1's c, lane+4's b
-        int iterations = 0;
-        for (;;) {
-            // red :1020  U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F): west + east + north + south, as mg_gs_wave.h
-            a = q * (b_w + b + c + c_s - ha);
-            d = q * (c + c_e + b_n + b - hd);
-            const double a_e = gsp_shift<0x101>(a), d_s = gsp_shift<0x114>(d), d_w = gsp_shift<0x111>(d), a_n = gsp_shift<0x104>(a);
-            // black :1043
-            b = q * (a + a_e + d + d_s - hb);
-            c = q * (d_w + d + a_n + a - hc);
-            ++iterations;
-            b_w = gsp_shift<0x111>(b);
-            c_s = gsp_shift<0x114>(c);
-            c_e = gsp_shift<0x101>(c);
-            b_n = gsp_shift<0x104>(b);
-            // residuals of the red points (:560): inv*(n + s + e + w - 4u) - f
-            const double ra = inv * (c + c_s + b + b_w - 4 * a) - fa;
-            const double rd = inv * (b_n + b + c_e + c - 4 * d) - fd;
-            const double part = keep * (fabs(ra) + fabs(rd));
-            if (iterations < 50000000 && __builtin_amdgcn_ballot_w64(part > thr_sure) != 0) continue;  // sum >= part > 2*thr: err > tol
-            const double rb = inv * (d + d_s + a_e + a - 4 * b) - fb;
-            const double rc = inv * (a_n + a + d + d_w - 4 * c) - fc;
-            double acc = keep * (fabs(ra) + fabs(rb) + fabs(rc) + fabs(rd));
+        const double thr = tol * denom, thr_hi = thr * (1.0 + 0x1p-48), thr_lo = thr * (1.0 - 0x1p-48);
+        // Judging an iterate without the norm.  The red update of the NEXT sweep, a' = 0.25*(S - h^2 F), is built from
+        // the very neighbour sum S the residual of that red point in THIS iterate is, r = inv*(S - 4a) - F:
+        // r = 4*inv*(a' - a) up to rounding, E <= eps*(60*inv*max|U| + 6*|F|), and the black residuals of an iterate
+        // (black was updated last) are rounding alone.  Zero start and |u_new| <= max|neighbours| + h^2|F|/4 give
+        // max|U| <= 2k*h^2*max|F|/4 after k sweeps, so E <= 64*k*eps*max|F| per point.  Hence
+        //   (1) a lane with 4*inv*|a' - a| > 2*thr has |r| > 1.5*thr: the norm's sum, all terms non-negative, is above;
+        //   (2) est = sum over the lanes of |a' - a| + |d' - d| is the norm's sum / (4*inv) to within 40*E/(4*inv): outside
+        //       a band of 2^-10 around the target it decides, inside the band the norm itself is computed;
+        //   (3) a half-sweep zeroes the residuals of its colour and moves a quarter of each to the (at most four)
+        //       neighbours of the other colour, so the L1 norm of the residual never grows from one iterate to the
+        //       next: an iterate followed, any number of sweeps later, by one that is certainly above the target was
+        //       above it too.
+        // All three hold while 40*64*k*eps*max|F| <= thr*2^-10, i.e. k <= thr*2^31/max|F| (7700 sweeps at the shipped
+        // tolerance and |F| = 1; the coarse right-hand side of a cycle is a residual, far smaller); past that every
+        // iterate gets the norm.  The solve therefore runs GS_BATCH sweeps between tests -- for the lone wave a test
+        // and its taken branch cost as much as a sweep and a half (scripts/ubench/gs_iter.hip) -- remembers the red
+        // values the batch started from (red-black: they ARE the state), and when a batch ends at or below the target
+        // goes back to them and repeats those sweeps judging each iterate: the stopping iterate, its bits and its
+        // number are the reference's.
+        constexpr int GS_BATCH = 8;
+        double fm = fmax(fmax(fabs(fa), fabs(fb)), fmax(fabs(fc), fabs(fd)));
+        fm = fmax(fm, gsw::row_shr_zero<1>(fm));
+        fm = fmax(fm, gsw::row_shr_zero<2>(fm));
+        fm = fmax(fm, gsw::row_shr_zero<4>(fm));
+        fm = fmax(fm, gsw::row_shr_zero<8>(fm));
+        const double f_max = gsw::read_lane(fm, 15), k_num = thr * 0x1p31;
+        int fast_until = 50000000;                 // the usual case, without the division; F = 0 lands here too
+        if (!(k_num >= 5e7 * f_max)) {             // (a NaN anywhere lands in this branch, and at 0)
+            const double k_safe = k_num / f_max;
+            fast_until = __builtin_amdgcn_readfirstlane(k_safe > 0.0 ? (int)k_safe : 0);
+        }
+        // h2 for 1/inv: the tests carry a margin of 2^-10 and more, the last bits of their thresholds are free
+        const double thr_e = 0.25 * thr * h2, thr_d = 2.0 * thr_e, thr_e_hi = thr_e * (1.0 + 0x1p-10), thr_e_lo = thr_e * (1.0 - 0x1p-10);
+        struct Iterate {
+            double a, b, c, d;              // the block: a, d red; b, c black
+            double a_e, d_s, d_w, a_n;      // lane+1's a, lane+4's d, lane-1's d, lane-4's a
+            double b_w, c_s, c_e, b_n;      // lane-1's b, lane-4's c, lane+1's c, lane+4's b
+        };
+        // one sweep: the red values (na, nd) prepared by the sweep before, the black half, and the red half of the next
+        // sweep kept aside until this iterate has been judged (:996)
+        auto sweep = [&](Iterate &s, double &na, double &nd) {
+            s.a = na;                       // red :1020, U = 0.25*(U[l] + U[r] + U[t] + U[b] - h^2 F)
+            s.d = nd;
+            s.a_e = gsp_shift<0x101>(s.a), s.d_s = gsp_shift<0x114>(s.d), s.d_w = gsp_shift<0x111>(s.d), s.a_n = gsp_shift<0x104>(s.a);
+            s.b = __builtin_fma(q, ((s.a + s.a_e) + s.d) + s.d_s, -qb);   // black :1043
+            s.c = __builtin_fma(q, ((s.d_w + s.d) + s.a_n) + s.a, -qc);
+            s.b_w = gsp_shift<0x111>(s.b);
+            s.c_s = gsp_shift<0x114>(s.c);
+            s.c_e = gsp_shift<0x101>(s.c);
+            s.b_n = gsp_shift<0x104>(s.b);
+            na = __builtin_fma(q, ((s.b_w + s.b) + s.c) + s.c_s, -qa);    // west + east + north + south, as mg_gs_wave.h
+            nd = __builtin_fma(q, ((s.c + s.c_e) + s.b_n) + s.b, -qd);
+        };
+        auto row_total = [](double acc) {
             acc += gsw::row_shr_zero<1>(acc);
             acc += gsw::row_shr_zero<2>(acc);
             acc += gsw::row_shr_zero<4>(acc);
             acc += gsw::row_shr_zero<8>(acc);       // lane 15 holds the total
-            const double sum = gsw::read_lane(acc, 15);
-            const bool above = sum > thr_hi ? true : (sum < thr_lo ? false : sum / denom > tol);  // :1059, :996
+            return gsw::read_lane(acc, 15);
+        };
+        // the norm itself (:560, :1051-1059): inv*(n + s + e + w - 4u) - f over the four points of the block
+        auto above_target = [&](const Iterate &s) {
+            const double ra = inv * (s.c + s.c_s + s.b + s.b_w - 4 * s.a) - fa;
+            const double rd = inv * (s.b_n + s.b + s.c_e + s.c - 4 * s.d) - fd;
+            const double rb = inv * (s.d + s.d_s + s.a_e + s.a - 4 * s.b) - fb;
+            const double rc = inv * (s.a_n + s.a + s.d + s.d_w - 4 * s.c) - fc;
+            const double sum = row_total(keep * (fabs(ra) + fabs(rb) + fabs(rc) + fabs(rd)));
+            return sum > thr_hi ? true : (sum < thr_lo ? false : sum / denom > tol);  // :1059, :996
+        };
+        Iterate u;
+        double na = -qa, nd = -qd;          // the first red half-sweep, from memset(U, 0) :993
+        int iterations = 0;
+        while (iterations + GS_BATCH <= fast_until) {
+            const double batch_a = na, batch_d = nd;
+#pragma unroll
+            for (int m = 0; m < GS_BATCH; ++m) sweep(u, na, nd);
+            const double step_a = fabs(na - u.a), step_d = fabs(nd - u.d);
+            bool above = __builtin_amdgcn_ballot_w64(fmax(step_a, step_d) > thr_d) != 0;              // (1)
+            if (!above) above = row_total(keep * (step_a + step_d)) > thr_e_hi;                       // (2)
+            if (!above) {                   // the stop lies in this batch: once more, judging every iterate
+                na = batch_a;
+                nd = batch_d;
+                break;
+            }
+            iterations += GS_BATCH;         // (3): and so were the iterates in between
+        }
+        for (;;) {
+            sweep(u, na, nd);
+            ++iterations;
+            bool above, decided = false;
+            if (iterations < fast_until) {
+                const double est = row_total(keep * (fabs(na - u.a) + fabs(nd - u.d)));               // (2)
+                above = est > thr_e_hi;
+                decided = above || est < thr_e_lo;
+            }
+            if (!decided) above = above_target(u);
             if (!above || iterations >= 50000000) break;
         }
         if (active) {
-            SRC(p00) = (real_t)a;
-            SRC(p00 + 1) = (real_t)b;
-            SRC(p00 + N) = (real_t)c;
-            SRC(p00 + N + 1) = (real_t)d;
+            SRC(p00) = (real_t)u.a;
+            SRC(p00 + 1) = (real_t)u.b;
+            SRC(p00 + N) = (real_t)u.c;
+            SRC(p00 + N + 1) = (real_t)u.d;
         }
         if (lane == 0) {
             state[0] = 1;
