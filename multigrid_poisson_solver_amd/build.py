@@ -74,6 +74,10 @@ def build(force=False, verbose=False):
                 # -cuid: hipcc derives the compilation-unit id (part of internal symbol names) from the source PATH by
                 # default; a fixed one per file keeps the library's bytes independent of where the tree lies
                 cmd = common + (["-x", "hip"] if s.endswith(".hip") else []) + ["-cuid=mg_" + os.path.basename(s).replace(".", "_"), "-c", s, "-o", o]
+                if os.path.basename(s).startswith("mg_tail"):
+                    # the coarse tail is one workgroup whose exact solver is ONE wave running a 2 KB loop: with the loop
+                    # heads on instruction-cache lines the solve measured 10 % faster (the streaming kernels: no change)
+                    cmd.insert(-4, "-falign-loops=64")
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True)

@@ -443,7 +443,8 @@ bool try_tail(Exec &x)
     static int traced = 0;
     long long *trace = nullptr;
     if (trace_on && traced < 3 && !x.capturing) {
-        (void)hipMalloc((void **)&trace, (k::TAIL_MAX_NODES + 2) * sizeof(long long));
+        (void)hipMalloc((void **)&trace, (k::TAIL_MAX_NODES + 2 + 24 * 8) * sizeof(long long));
+        (void)hipMemset(trace, 0, (k::TAIL_MAX_NODES + 2 + 24 * 8) * sizeof(long long));
         a.trace = trace;
     }
     {
@@ -454,12 +455,22 @@ bool try_tail(Exec &x)
         std::vector<long long> t((size_t)a.n_nodes + 2);
         (void)hipStreamSynchronize(x.c.stream);
         (void)hipMemcpy(t.data(), trace, t.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        (void)hipFree(trace);
         ++traced;
         fprintf(stderr, "[tail trace] staging %.2f us;", (double)(t[1] - t[0]) * 0.01);
         for (int i = 0; i < a.n_nodes; ++i)
             fprintf(stderr, " %d@%d:%.2f", a.nodes[i].type, a.N[node_level[i]], (double)(t[(size_t)i + 2] - t[(size_t)i + 1]) * 0.01);
         fprintf(stderr, " us\n");
+#ifdef MG_TAIL_PHASES   // shader-clock cycles between the stamps of thread 0 inside the first nodes (mg_tail_impl.h: PHASE)
+        std::vector<long long> ph(24 * 8);
+        (void)hipMemcpy(ph.data(), trace + k::TAIL_MAX_NODES + 2, ph.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        for (int i = 0; i < a.n_nodes && i < 24; ++i) {
+            if (a.nodes[i].type == 0) continue;
+            fprintf(stderr, "[tail phases] %2d@%-3d cycles:", a.nodes[i].type, a.N[node_level[i]]);
+            for (int k = 1; k < 8 && ph[(size_t)i * 8 + k]; ++k) fprintf(stderr, " %lld", ph[(size_t)i * 8 + k] - ph[(size_t)i * 8 + k - 1]);
+            fprintf(stderr, "\n");
+        }
+#endif
+        (void)hipFree(trace);
     }
     x.tok = tok;
     return true;

@@ -475,33 +475,6 @@ __device__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F
     __syncthreads();
 }
 
-// offset of level l's three arrays (U, partner, F) in the LDS array
-__device__ __forceinline__ int level_base(const TailArgsT<real_t> &a, int l)
-{
-    int o = 0;
-#pragma unroll
-    for (int k = 0; k < TAIL_MAX_LEVELS; ++k)
-        if (k < l) o += 3 * a.N[k] * a.N[k];
-    return o;
-}
-// transfer tables of level pair l (l <-> l+1) staged in LDS: reals  w[M] rhi[N] rlo[N] chi[N] clo[N]
-// from a.tab_real0 (in real_t units), ints  lo[M] orow[N] ocol[N]  from a.tab_int0 (in int units)
-__device__ __forceinline__ int real_tab(const TailArgsT<real_t> &a, int l)
-{
-    int o = a.tab_real0;
-#pragma unroll
-    for (int k = 0; k < TAIL_MAX_LEVELS - 1; ++k)
-        if (k < l) o += a.N[k + 1] + 4 * a.N[k];
-    return o;
-}
-__device__ __forceinline__ int int_tab(const TailArgsT<real_t> &a, int l)
-{
-    int o = a.tab_int0;
-#pragma unroll
-    for (int k = 0; k < TAIL_MAX_LEVELS - 1; ++k)
-        if (k < l) o += a.N[k + 1] + 2 * a.N[k];
-    return o;
-}
 #define ITAB(i) (reinterpret_cast<int *>(lds)[(i)])
 
 // first double past the level arrays (fp32 fields only: fp64 scratch of the exact solver)
@@ -512,22 +485,75 @@ __host__ __device__ __forceinline__ int gs_scratch(const TailArgsT<real_t> &a)
     return (int)((elems * sizeof(real_t) + 7) / 8);
 }
 
+// diagnostics (-DMG_TAIL_PHASES, with MG_TAIL_TRACE=1): shader-clock stamps of thread 0 inside the first 24 nodes
+#ifdef MG_TAIL_PHASES
+#define PHASE(k) do { if (a.trace && threadIdx.x == 0 && i < 24) a.trace[TAIL_MAX_NODES + 2 + i * 8 + (k)] = clock64(); } while (0)
+#else
+#define PHASE(k) do { } while (0)
+#endif
+
+// lane l's value of a per-lane table, for a wave-uniform l
+__device__ __forceinline__ int lane_get(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float lane_get(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_get(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a)
 {
     __shared__ double sm[17];                 // block_total of the block Gauss-Seidel
     __shared__ double slots[2][TAIL_WAVES];   // error partials, alternating between nodes
+    // The node program and the per-level constants live in the LANES of a few registers of every wave (lane i: node i,
+    // lane l: level l) and are fetched with v_readlane.  Read from the kernel arguments with a run-time index they are
+    // scalar loads, and a lone dependent scalar load costs a wave ~250 cycles: several per node, and one in every
+    // sweep for the offset of the level's arrays, were a third of a node's time on the 16 x 16 level.
+    const int tab_lane = threadIdx.x & 63;
+    int lv_where = 0, lv_tabs = 0;            // base | N << 16;  real tables | int tables << 16  (offsets < 2^16: 160 KB of LDS)
+    real_t lv_dx2 = 0, lv_inv = 0, lv_cdx = 1, lv_crcp = 1;
+    double lv_gs_h2 = 0, lv_gs_inv = 0;
+    if (tab_lane < a.n_levels) {
+        int base = 0, rt = a.tab_real0, it = a.tab_int0;
+#pragma unroll
+        for (int k = 0; k < TAIL_MAX_LEVELS - 1; ++k)
+            if (k < tab_lane) {
+                base += 3 * a.N[k] * a.N[k];
+                rt += a.N[k + 1] + 4 * a.N[k];   // reals  w[M] rhi[N] rlo[N] chi[N] clo[N]  of level pair k <-> k+1
+                it += a.N[k + 1] + 2 * a.N[k];   // ints   lo[M] orow[N] ocol[N]
+            }
+        lv_where = base | (a.N[tab_lane] << 16);
+        lv_tabs = rt | (it << 16);
+        lv_dx2 = a.dx2[tab_lane];
+        lv_inv = a.inv[tab_lane];
+        lv_gs_h2 = a.gs_h2[tab_lane];
+        lv_gs_inv = a.gs_inv[tab_lane];
+        if (tab_lane + 1 < a.n_levels) {
+            lv_cdx = a.c_dx[tab_lane];
+            lv_crcp = real_t(1.0) / lv_cdx;
+        }
+    }
+    int nd_what = 1, nd_err = -1;             // type + 1 | steps << 2
+    double nd_tol = 0.0;
+    if (tab_lane < a.n_nodes) {
+        nd_what = (a.nodes[tab_lane].type + 1) | (a.nodes[tab_lane].steps << 2);
+        nd_err = a.nodes[tab_lane].err_slot;
+        nd_tol = a.nodes[tab_lane].tol;
+    }
+    auto N_of = [&](int l) { return lane_get(lv_where, l) >> 16; };
+    auto real_tab_of = [&](int l) { return lane_get(lv_tabs, l) & 0xffff; };
+    auto int_tab_of = [&](int l) { return (int)((unsigned)lane_get(lv_tabs, l) >> 16); };
     unsigned swapped = 0;  // bit l: level l's U currently lives in its second buffer (same in every thread)
-    auto U_of = [&](int l) { return level_base(a, l) + (((swapped >> l) & 1u) ? a.N[l] * a.N[l] : 0); };
-    auto T_of = [&](int l) { return level_base(a, l) + (((swapped >> l) & 1u) ? 0 : a.N[l] * a.N[l]); };
-    auto F_of = [&](int l) { return level_base(a, l) + 2 * a.N[l] * a.N[l]; };
+    auto U_of = [&](int l) { const int w = lane_get(lv_where, l), n = w >> 16; return (w & 0xffff) + (((swapped >> l) & 1u) ? n * n : 0); };
+    auto T_of = [&](int l) { const int w = lane_get(lv_where, l), n = w >> 16; return (w & 0xffff) + (((swapped >> l) & 1u) ? 0 : n * n); };
+    auto F_of = [&](int l) { const int w = lane_get(lv_where, l), n = w >> 16; return (w & 0xffff) + 2 * n * n; };
     if (a.trace && threadIdx.x == 0) a.trace[0] = wall_clock64();
     {
         // stage the finest source and all transfer tables: one global round trip for the launch
-        const int N0 = a.N[0], f0 = F_of(0);
+        const int N0 = N_of(0), f0 = F_of(0);
         for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) lds[f0 + p] = a.F_top[p];
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int l = 0; l + 1 < a.n_levels; ++l) {
-            const int N = a.N[l], M = a.N[l + 1], rt = real_tab(a, l), it = int_tab(a, l);
+            const int N = N_of(l), M = N_of(l + 1), rt = real_tab_of(l), it = int_tab_of(l);
             for (int i = lane; i < N; i += 64) {
                 if (wave == 0 && i < M) lds[rt + i] = a.r_w[l][i];
                 if (wave == 1) lds[rt + M + i] = a.p_rhi[l][i];
@@ -544,9 +570,26 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     if (a.trace && threadIdx.x == 0) a.trace[1] = wall_clock64();
 
     int cur = 0, parity = 0;
-    for (int i = 0; i < a.n_nodes; ++i) {
-        const TailNode nd = a.nodes[i];
+    // The error of a node's smoothing (:621-622: sixteen partial sums, two divisions, a store) is finished by the LAST
+    // wave at the start of the next node: on the small levels and during the exact solve that wave owns no points,
+    // and the 600 cycles leave the critical path.
+    int pend_slot = -1, pend_N = 0, pend_parity = 0;
+    auto flush_error = [&]() {
+        if (pend_slot >= 0 && threadIdx.x == TAIL_THREADS - 64) finish_error(slots[pend_parity], pend_N, a.err_dev + pend_slot);
+        pend_slot = -1;
+    };
+    const int n_nodes = a.n_nodes;
+    for (int i = 0; i < n_nodes; ++i) {
+        TailNode nd;
+        {
+            const int w = lane_get(nd_what, i);
+            nd.type = (w & 3) - 1;
+            nd.steps = w >> 2;
+            nd.err_slot = lane_get(nd_err, i);
+            nd.tol = lane_get(nd_tol, i);
+        }
         if (a.trace && threadIdx.x == 0 && i > 0) a.trace[1 + i] = wall_clock64();
+        flush_error();
         // A wave none of whose threads owns a point of this node's level (N = 16: 12 of the 16 waves) only
         // keeps the barrier count: the four waves of a SIMD issue in turn, so every instruction an idle wave
         // runs through delays the wave next to it that has the work.
@@ -555,20 +598,22 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
         const int wave_first = __builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63;
         if (nd.type == -1) {
             // memset(U,0) :256, doSmoothing :259, getResidual :268, sign flip :277-280, doRestriction :287
-            const int N = a.N[cur];
+            const int N = N_of(cur);
             if (wave_first >= N * N) {
                 if ((threadIdx.x & 63) == 0) slots[parity][threadIdx.x >> 6] = 0.0;
                 for (int b = 0; b < nd.steps + 2; ++b) __syncthreads();
                 if ((nd.steps - 1) & 1) swapped ^= 1u << cur;
+                pend_slot = nd.err_slot, pend_N = N, pend_parity = parity;
                 parity ^= 1;
                 ++cur;
                 continue;
             }
             auto down = [&](auto np_tag) {
             constexpr int NP = decltype(np_tag)::value;
+            PHASE(0);
             const int F = F_of(cur);
             const PointsT<NP> P = map_points<NP>(N);
-            const real_t dx2 = a.dx2[cur], inv = a.inv[cur];
+            const real_t dx2 = lane_get(lv_dx2, cur), inv = lane_get(lv_inv, cur);
             real_t v[NP], f[NP], h2f[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -576,11 +621,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
                 h2f[k] = dx2 * f[k];
                 v[k] = 0.0;
             }
+            PHASE(1);
             sweep<true, NP>(P, N, 0, U_of(cur), v, h2f);
+            PHASE(2);
             for (int s = 1; s < nd.steps; ++s) {
                 sweep<false, NP>(P, N, U_of(cur), T_of(cur), v, h2f);
                 swapped ^= 1u << cur;
             }
+            PHASE(3);
             // residual once per point: the error norm (:607-622) and, negated, the restriction's input
             const int src = U_of(cur), D = T_of(cur);
             double acc = 0.0;
@@ -597,10 +645,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             }
             post_partial(acc, slots[parity]);
             __syncthreads();
-            if (threadIdx.x == 0 && nd.err_slot >= 0) finish_error(slots[parity], N, a.err_dev + nd.err_slot);
+            PHASE(4);
+            pend_slot = nd.err_slot, pend_N = N, pend_parity = parity;
+            PHASE(5);
             parity ^= 1;
-            const int M = a.N[cur + 1], Fc = F_of(cur + 1);
-            const int rt = real_tab(a, cur), it = int_tab(a, cur);
+            const int M = N_of(cur + 1), Fc = F_of(cur + 1);
+            const int rt = real_tab_of(cur), it = int_tab_of(cur);
             const PointsT<1> Q = map_points<1>(M);  // M <= 32: one coarse point per thread at most
 #pragma unroll
             for (int k = 0; k < 1; ++k) {
@@ -620,35 +670,39 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             else if (N * N <= 2 * TAIL_THREADS) down(std::integral_constant<int, 2>{});
             else down(std::integral_constant<int, PT>{});
             __syncthreads();
+            PHASE(6);
             ++cur;
         } else if (nd.type == 0) {
-            const int N = a.N[cur];
+            const int N = N_of(cur);
+            const double gs_h2 = lane_get(lv_gs_h2, cur), gs_inv = lane_get(lv_gs_inv, cur);
             if (N * N <= 64 && (N & 1) == 0 && N >= 4) {
-                gauss_seidel_blocks(N, a.gs_h2[cur], a.gs_inv[cur], U_of(cur), F_of(cur), nd.tol, a.gs_state);
+                gauss_seidel_blocks(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a.gs_state);
             } else if (N * N <= 64) {
-                gauss_seidel_wave(N, a.gs_h2[cur], a.gs_inv[cur], U_of(cur), F_of(cur), nd.tol, a.gs_state);
+                gauss_seidel_wave(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a.gs_state);
             } else if (N * N <= 64 * GS_WAVE_PTS) {
                 // fp64 fields: the level's own U array is the solver's array; fp32 fields: the fp64 scratch
                 const bool in_place = sizeof(real_t) == sizeof(double);
-                gauss_seidel_wave_lds(N, a.gs_h2[cur], a.gs_inv[cur], in_place ? U_of(cur) : gs_scratch(a), in_place, U_of(cur), F_of(cur),
+                gauss_seidel_wave_lds(N, gs_h2, gs_inv, in_place ? U_of(cur) : gs_scratch(a), in_place, U_of(cur), F_of(cur),
                                       nd.tol, a.gs_state);
-            } else gauss_seidel_level(N, a.gs_h2[cur], a.gs_inv[cur], U_of(cur), F_of(cur), gs_scratch(a), nd.tol, sm, a.gs_state);
+            } else gauss_seidel_level(N, gs_h2, gs_inv, U_of(cur), F_of(cur), gs_scratch(a), nd.tol, sm, a.gs_state);
             __syncthreads();
         } else {  // 1: doProlongation :354, doGridAddition :368, doSmoothing :416
-            const int Nc = a.N[cur], fine = cur - 1, N = a.N[fine];
+            const int Nc = N_of(cur), fine = cur - 1, N = N_of(fine);
             if (wave_first >= N * N) {
                 if ((threadIdx.x & 63) == 0) slots[parity][threadIdx.x >> 6] = 0.0;
                 for (int b = 0; b < nd.steps + 2; ++b) __syncthreads();
                 if (nd.steps & 1) swapped ^= 1u << fine;
+                pend_slot = nd.err_slot, pend_N = N, pend_parity = parity;
                 parity ^= 1;
                 --cur;
                 continue;
             }
             auto up = [&](auto np_tag) {
             constexpr int NP = decltype(np_tag)::value;
+            PHASE(0);
             const int uc = U_of(cur), F = F_of(fine);
-            const int rt = real_tab(a, fine) + Nc, it = int_tab(a, fine) + Nc;  // past w[M] / lo[M]
-            const real_t c_dx = a.c_dx[fine], c_rcp = real_t(1.0) / c_dx, dx2 = a.dx2[fine], inv = a.inv[fine];
+            const int rt = real_tab_of(fine) + Nc, it = int_tab_of(fine) + Nc;  // past w[M] / lo[M]
+            const real_t c_dx = lane_get(lv_cdx, fine), c_rcp = lane_get(lv_crcp, fine), dx2 = lane_get(lv_dx2, fine), inv = lane_get(lv_inv, fine);
             const PointsT<NP> P = map_points<NP>(N);
             real_t v[NP], f[NP], h2f[NP];
             {
@@ -675,10 +729,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
                 }
             }
             __syncthreads();
+            PHASE(1);
             for (int s = 0; s < nd.steps; ++s) {
                 sweep<false, NP>(P, N, U_of(fine), T_of(fine), v, h2f);
                 swapped ^= 1u << fine;
             }
+            PHASE(2);
             const int src = U_of(fine);
             double acc = 0.0;
 #pragma unroll
@@ -690,7 +746,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             }
             post_partial(acc, slots[parity]);
             __syncthreads();
-            if (threadIdx.x == 0 && nd.err_slot >= 0) finish_error(slots[parity], N, a.err_dev + nd.err_slot);
+            PHASE(3);
+            pend_slot = nd.err_slot, pend_N = N, pend_parity = parity;
+            PHASE(4);
             };
             if (N * N <= TAIL_THREADS) up(std::integral_constant<int, 1>{});
             else if (N * N <= 2 * TAIL_THREADS) up(std::integral_constant<int, 2>{});
@@ -699,9 +757,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             --cur;
         }
     }
+    flush_error();
     if (a.trace && threadIdx.x == 0) a.trace[1 + a.n_nodes] = wall_clock64();
     {
-        const int N0 = a.N[0], u0 = U_of(0);
+        const int N0 = N_of(0), u0 = U_of(0);
         for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) a.U_top[p] = lds[u0 + p];
     }
 }
