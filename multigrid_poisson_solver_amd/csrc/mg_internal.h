@@ -277,6 +277,7 @@ void tail_launch(hipStream_t s, const TailArgs &a);
 // red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]
 void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol,
                   int *state);
+void gauss_seidel_blocks_launch(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol, int *state);
 int  gs_single_workgroup_max_n();
 }  // namespace k
 

@@ -749,6 +749,10 @@ void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const 
 {
     (void)hipMemsetAsync(state, 0, 4 * sizeof(int), s);
     const size_t n = (size_t)N * N;
+    if (n <= 64 && N >= 4 && (N & 1) == 0) {  // 4 x 4, 6 x 6, 8 x 8: the block solver of the coarse tail
+        gauss_seidel_blocks_launch(s, N, h2, inv, U, F, tol, state);
+        return;
+    }
     if (n <= 64) {
         hipLaunchKernelGGL(k_gs_wave, dim3(1), dim3(64), 0, s, N, h2, inv, U, F, tol, state);
         return;

@@ -141,14 +141,16 @@ __device__ __forceinline__ void post_partial(double acc, double *slots)
     const double t = gsw::wave_total(acc);  // all 64 lanes are here
     if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = t;
 }
-// last stage, thread 0 only, after a barrier: fixed-order sum, (sum1 + sum2)/N/N  (:621-622)
+// last stage, one thread, after a barrier: fixed-order sum, (sum1 + sum2)/N/N  (:621-622); a division by a power of
+// two is a change of exponent (v_ldexp_f64; like the division, correctly rounded should the result be subnormal)
 __device__ __forceinline__ void finish_error(const double *slots, int N, double *out)
 {
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < TAIL_WAVES; ++i) s += slots[i];
     double e = s + s;
-    e = e / N / N;
+    if ((N & (N - 1)) == 0) e = ldexp(e, -2 * (31 - __builtin_clz(N)));
+    else e = e / N / N;
     *out = e;
 }
 
@@ -337,7 +339,7 @@ __device__ __forceinline__ double gsp_shift(double v)  // in-row DPP shift, zero
 }
 
 // wave 0 solves, the other waves wait at the closing barrier; N even, 4 <= N <= 8
-__device__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F, double tol, int *state)
+__device__ __forceinline__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F, double tol, int *state)
 {
     const int tid = threadIdx.x;
     if (tid < N * N) SRC(tid) = real_t(0.0);        // the rim (and, for now, everything else)
@@ -433,7 +435,7 @@ __device__ void gauss_seidel_blocks(int N, double h2, double inv, int src, int F
             return sum > thr_hi ? true : (sum < thr_lo ? false : sum / denom > tol);  // :1059, :996
         };
         Iterate u;
-        double na = -qa, nd = -qd;          // the first red half-sweep, from memset(U, 0) :993
+        double na = 0.0 - qa, nd = 0.0 - qd;   // the first red half-sweep, from memset(U, 0) :993  (0 - 0 = +0, as 0.25*(0 - h^2*0))
         int iterations = 0;
         while (iterations + GS_BATCH <= fast_until) {
             const double batch_a = na, batch_d = nd;

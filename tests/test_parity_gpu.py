@@ -179,6 +179,22 @@ def test_exact_solver_vs_oracle(mg, oracle, N):
     assert_bits(U.to_host(), want, f"GaussSeidel N={N}")
 
 
+@pytest.mark.parametrize("N", [4, 6, 8])
+@pytest.mark.parametrize("scale,tol", [(0.0, 1e-7), (1e-6, 1e-7), (1.0, 1e-7), (1.0, 1e-3), (1.0, 1e-11), (1e2, 1e-7), (1e3, 1e-7),
+                                       (1e4, 1e-7), (1e9, 1e-2), (1e-3, 1e-12)])
+def test_block_exact_solver_scales_and_targets(mg, oracle, N, scale, tol):
+    """The block solver of the coarse tail (even grids up to 8 x 8) judges most iterates without the norm, in batches,
+    under a bound that depends on max|F| / tolerance: right-hand sides from zero to 1e9 walk through every path of it
+    (all batches certain; the stop inside the first batch; the bound exhausted after a few sweeps, so that the norm is
+    computed on every iterate) -- U bit for bit and the iteration count against the oracle."""
+    F = (np.random.default_rng(100 * N + int(np.log10(scale + 1e-30)) % 97).random((N, N)) - 0.5) * scale
+    Fd, U = mg.DeviceGrid.from_host(F), mg.DeviceGrid.from_host(np.full((N, N), 3.0))
+    mg.doExactSolver(N, 1.0, U, Fd, tol, 1)
+    want = oracle.doExactSolver(N, 1.0, F, tol)
+    assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    assert_bits(U.to_host(), want, f"block GaussSeidel N={N} scale={scale} tol={tol}")
+
+
 def test_exact_solver_multi_workgroup_path(mg, oracle):
     N = 160  # above the single-workgroup LDS limit
     F = np.random.default_rng(5).random((N, N)) - 0.5
