@@ -130,6 +130,10 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
 
 
 def run(args, rank, world, local_rank):
+    # a rank that waits for ever on a neighbour (a lost peer, a wedged collective) ends with its stacks on stderr and a
+    # non-zero exit instead of holding the node until the driver's own limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("MG_BENCH_DEADLINE", "900")), exit=True)
     rehearsal = os.environ.get("MG_BENCH_TRANSPORT", "rccl") == "host"
     if rehearsal:
         local_rank = 0  # every rank on the one GPU
@@ -197,3 +201,4 @@ def run(args, rank, world, local_rank):
     mg.finalize()
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()

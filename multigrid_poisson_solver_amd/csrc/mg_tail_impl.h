@@ -39,7 +39,10 @@ namespace MG_REAL_NS {
 typedef MG_REAL real_t;
 
 
-constexpr int TAIL_THREADS = 1024;
+#ifndef MG_TAIL_THREADS
+#define MG_TAIL_THREADS 1024
+#endif
+constexpr int TAIL_THREADS = MG_TAIL_THREADS;
 constexpr int TAIL_WAVES = TAIL_THREADS / 64;
 
 // every point of an N x N LDS grid, rows over waves, columns over lanes: no integer division
@@ -556,15 +559,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int l = 0; l + 1 < a.n_levels; ++l) {
             const int N = N_of(l), M = N_of(l + 1), rt = real_tab_of(l), it = int_tab_of(l);
+            constexpr int W = TAIL_WAVES < 8 ? TAIL_WAVES : 8;   // the eight tables over the first W waves
             for (int i = lane; i < N; i += 64) {
-                if (wave == 0 && i < M) lds[rt + i] = a.r_w[l][i];
-                if (wave == 1) lds[rt + M + i] = a.p_rhi[l][i];
-                if (wave == 2) lds[rt + M + N + i] = a.p_rlo[l][i];
-                if (wave == 3) lds[rt + M + 2 * N + i] = a.p_chi[l][i];
-                if (wave == 4) lds[rt + M + 3 * N + i] = a.p_clo[l][i];
-                if (wave == 5 && i < M) ITAB(it + i) = a.r_lo[l][i];
-                if (wave == 6) ITAB(it + M + i) = a.p_orow[l][i];
-                if (wave == 7) ITAB(it + M + N + i) = a.p_ocol[l][i];
+                if (wave == 0 % W && i < M) lds[rt + i] = a.r_w[l][i];
+                if (wave == 1 % W) lds[rt + M + i] = a.p_rhi[l][i];
+                if (wave == 2 % W) lds[rt + M + N + i] = a.p_rlo[l][i];
+                if (wave == 3 % W) lds[rt + M + 2 * N + i] = a.p_chi[l][i];
+                if (wave == 4 % W) lds[rt + M + 3 * N + i] = a.p_clo[l][i];
+                if (wave == 5 % W && i < M) ITAB(it + i) = a.r_lo[l][i];
+                if (wave == 6 % W) ITAB(it + M + i) = a.p_orow[l][i];
+                if (wave == 7 % W) ITAB(it + M + N + i) = a.p_ocol[l][i];
             }
         }
     }
@@ -653,9 +657,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             parity ^= 1;
             const int M = N_of(cur + 1), Fc = F_of(cur + 1);
             const int rt = real_tab_of(cur), it = int_tab_of(cur);
-            const PointsT<1> Q = map_points<1>(M);  // M <= 32: one coarse point per thread at most
+            constexpr int NQ = (TAIL_MAX_N / 2) * (TAIL_MAX_N / 2) <= TAIL_THREADS ? 1 : (NP + 3) / 4;  // coarse points per thread
+            const PointsT<NQ> Q = map_points<NQ>(M);
 #pragma unroll
-            for (int k = 0; k < 1; ++k) {
+            for (int k = 0; k < NQ; ++k) {
                 if (!Q.live[k]) continue;
                 real_t vc = 0.0;
                 if (Q.inner[k]) {
@@ -670,6 +675,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             };
             if (N * N <= TAIL_THREADS) down(std::integral_constant<int, 1>{});
             else if (N * N <= 2 * TAIL_THREADS) down(std::integral_constant<int, 2>{});
+            else if (PT > 4 && N * N <= 4 * TAIL_THREADS) down(std::integral_constant<int, 4>{});
             else down(std::integral_constant<int, PT>{});
             __syncthreads();
             PHASE(6);
@@ -754,6 +760,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             };
             if (N * N <= TAIL_THREADS) up(std::integral_constant<int, 1>{});
             else if (N * N <= 2 * TAIL_THREADS) up(std::integral_constant<int, 2>{});
+            else if (PT > 4 && N * N <= 4 * TAIL_THREADS) up(std::integral_constant<int, 4>{});
             else up(std::integral_constant<int, PT>{});
             parity ^= 1;
             --cur;
