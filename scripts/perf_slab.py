@@ -16,7 +16,7 @@ reps = 10
 mg.init(0)
 path = os.path.join(tempfile.mkdtemp(), "v.txt")
 mg.write_vcycle_file(path, N, 8, 3, 1e-7)
-plan = mg.SlabPlan(path, R, -1, 1024)
+plan = mg.SlabPlan(path, R, -1, int(os.environ.get("MG_COLLAPSE_N", "1024")))
 plan.want_error(False)
 for _ in range(3):
     plan.execute()
