@@ -103,7 +103,7 @@ struct StreamParams {
     double *out_wide;               // fp32 fields only: store the result as fp64 here instead of `out`
     int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
     int raw_norm;                   // error output is the raw sum over the owned rows
-    int nt_min_n;                   // grids at least this large store U/D non-temporally
+    int nt_min_n;                   // fused `1` nodes of grids at least this large store U non-temporally
     int fc_base, fc_rows;           // RESTRICT: window of Fc (global row of its first local row, rows)
     // IN_PROLONG: coarse grid and the host-built tables of doProlongation
     const real_t *coarse;
@@ -200,18 +200,19 @@ __device__ __forceinline__ Row<COLS> load_row(const real_t *__restrict__ row, un
     return r;
 }
 
-// nt: the array is far larger than the caches and is next read by a later kernel: a
-// non-temporal store keeps it from displacing the halo rows and coarse rows the neighbouring
-// tiles re-read (wave-uniform flag, set for N >= 2048)
-template <int COLS>
-__device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col_bytes, const Row<COLS> &r, bool nt)
+// NT: the array is far larger than the caches and is next read by a later kernel: a non-temporal store keeps it from
+// displacing the rows the neighbouring tiles re-read.  A COMPILE-TIME property of the kernel: as a run-time flag
+// (`if (nt) nontemporal store; else store`) the two branches are merged into one plain store by the compiler and the
+// hint is silently lost -- which is what the round-1/2 kernels ran with until this was noticed in the ISA.
+template <int COLS, bool NT>
+__device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col_bytes, const Row<COLS> &r)
 {
     char *a = reinterpret_cast<char *>(row) + col_bytes;
     if constexpr (COLS == 2) {
         real2_t t;
         t.x = r.v[0];
         t.y = r.v[1];
-        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real2_t *>(a));
+        if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<real2_t *>(a));
         else *reinterpret_cast<real2_t *>(a) = t;
     } else if constexpr (COLS == 4) {
         real4_t t;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void store_row(real_t *__restrict__ row, unsigned col
         t.y = r.v[1];
         t.z = r.v[2];
         t.w = r.v[3];
-        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<real4_t *>(a));
+        if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<real4_t *>(a));
         else *reinterpret_cast<real4_t *>(a) = t;
     } else {
         *reinterpret_cast<real_t *>(a) = r.v[0];
@@ -292,7 +293,7 @@ __device__ __forceinline__ CoarseV<NCV> load_coarse_local(const real_t *__restri
     return c;
 }
 
-template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || COLS == 4 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
@@ -356,7 +357,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     }
     const bool lane_loads = col_in[0] && col_in[COLS - 1];  // COLS == 2: N even, xl even
     const real_t dx2 = p.dx2, inv = p.inv;
-    const bool nt_stores = N >= p.nt_min_n;
     const bool want_res = RESTRICT || p.D != nullptr || p.part != nullptr;
     // clamped column of this lane's loads (lanes left/right of the grid re-read a valid pair); lane offsets in
     // bytes, see load_row
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                             for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
                         }
                     } else {
-                        store_row<COLS>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.out) + st_off), col_st, nw, nt_stores);
+                        store_row<COLS, NT>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.out) + st_off), col_st, nw);
                     }
                 }
             }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     acc += fabs(bits_and((double)r, am));
                 }
                 if (mine_row && lane_owns && p.D)
-                    store_row<COLS>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, d, nt_stores);
+                    store_row<COLS, false>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, d);
 
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
@@ -803,13 +803,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
 // this instantiation x CUs) where the grid is large enough, never fewer than 8 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
-template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT>
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false>
 void launch_k(hipStream_t s, StreamParams p, double *err_out)
 {
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT, PF>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -850,7 +850,7 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         if (!p.part) return;
     }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
 #ifdef MG_STREAM_TRACE
     {
         long long t[4];
@@ -897,6 +897,10 @@ template <int S, int PF>
 void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
 {
     const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
+    // non-temporal stores of U: the fused `1` node of the biggest levels only (measured with real nt stores, three
+    // alternating runs per build in one session: 358 -> 347 us at N = 8192; at 4096 a loss, 109 -> 118 us: the next
+    // launch reads that U as its coarse input; the `-1` node loses 4 % with them: MG_NT_MIN_N, default 8192)
+    const bool nt = p.N >= p.nt_min_n;
     if constexpr (sizeof(real_t) == 4) {
         // fp32 fields, 16 B per lane: the same kernel with 4 columns per lane (8 B per lane leaves it bound by its
         // instruction stream at half the bytes per instruction of the fp64 build)
@@ -905,7 +909,8 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
                 if (zero) launch_k<S, 4, IN_ZERO, true, PF>(s, p, err_out);
                 else launch_k<S, 4, IN_LOAD, true, PF>(s, p, err_out);
             } else if (prolong_in) {
-                launch_k<S, 4, IN_PROLONG, false, PF>(s, p, err_out);
+                if (nt) launch_k<S, 4, IN_PROLONG, false, PF, true>(s, p, err_out);
+                else launch_k<S, 4, IN_PROLONG, false, PF>(s, p, err_out);
             } else {
                 if (zero) launch_k<S, 4, IN_ZERO, false, PF>(s, p, err_out);
                 else launch_k<S, 4, IN_LOAD, false, PF>(s, p, err_out);
@@ -920,7 +925,8 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
-        launch_k<S, 2, IN_PROLONG, false, PF>(s, p, err_out);
+        if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true>(s, p, err_out);
+        else launch_k<S, 2, IN_PROLONG, false, PF>(s, p, err_out);
     } else {
         if (zero) launch_k<S, 2, IN_ZERO, false, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, false, PF>(s, p, err_out);
@@ -975,7 +981,7 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.raw_norm = fine_w ? 1 : 0;
     static const int cols4_min = [] { const char *e = getenv("MG_F32_COLS4_MIN_N"); return e ? atoi(e) : 8192; }();  // (measured: a gain only where the launch is bandwidth-bound, N >= 8192)
     p.cols4 = (sizeof(real_t) == 4 && N % 4 == 0 && N >= cols4_min && (!coarse || tb.p_cols4_ok)) ? 1 : 0;
-    static const int nt_min = [] { const char *e = getenv("MG_NT_MIN_N"); return e ? atoi(e) : 2048; }();
+    static const int nt_min = [] { const char *e = getenv("MG_NT_MIN_N"); return e ? atoi(e) : 8192; }();
     p.nt_min_n = nt_min;
     if (coarse) {
         p.coarse_base = coarse_w ? coarse_w->base : 0;
