@@ -23,6 +23,8 @@ os.environ.setdefault("MG_SLAB_POISON", "1")
 # the 4-columns-per-lane form of the fp32 kernels is the product's choice from N = 8192 on (where it pays); the tests
 # take it from N = 1024 on, so that the numpy restatement can check it bit for bit at sizes it finishes in seconds
 os.environ.setdefault("MG_F32_COLS4_MIN_N", "1024")
+# likewise the instantiation of the fused `1` node with non-temporal stores (the product: N >= 8192)
+os.environ.setdefault("MG_NT_MIN_N", "1024")
 
 
 def pytest_configure(config):
