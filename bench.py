@@ -70,15 +70,19 @@ def vcycle_algorithmic_bytes(sizes, nu1, nu2):
     return total
 
 
-def vcycle_compulsory_bytes(sizes):
+RECOMPUTE_MIN_N = int(os.environ.get("MG_RECOMPUTE_MIN_N", "4096"))  # the library's default (mg_abi.cpp: recompute_available)
+
+
+def vcycle_compulsory_bytes(sizes, recompute=True):
     """HBM bytes one V-cycle of the FUSED driver cannot avoid: per level one `-1` launch (F in, U out, coarse F
-    out: 16 n + 8 m) and one `1` launch (U, F, coarse U in, U out: 24 n + 8 m).  The coarse tail (N <= 64) lives
-    in LDS and is not counted."""
+    out: 16 n + 8 m) and one `1` launch (U, F, coarse U in, U out: 24 n + 8 m); from N = 4096 on the pair neither
+    writes nor re-reads the pre-smoothed U (the `1` node recomputes it): 8 n + 8 m and 16 n + 8 m.  The coarse tail
+    (N <= 64) lives in LDS and is not counted."""
     total = 0.0
     for a, b in zip(sizes[:-1], sizes[1:]):
         if a <= 64:
             break
-        total += 40.0 * a * a + 16.0 * b * b
+        total += (24.0 if recompute and a >= RECOMPUTE_MIN_N else 40.0) * a * a + 16.0 * b * b
     return total
 
 
@@ -126,10 +130,10 @@ def compulsory_bytes(kernel_family, N):
     n = float(N) * N
     if "widen" in kernel_family:   # fp32 `1` node that stores its result in fp64: counted in fp64-equivalent units (x 0.5 later)
         return 24.0 * n + 8.0 * (N // 2) ** 2 + 8.0 * n
-    if "restrict" in kernel_family:
-        return 16.0 * n + 8.0 * (N // 2) ** 2
-    if "prolong" in kernel_family:
-        return 24.0 * n + 8.0 * (N // 2) ** 2
+    if "restrict" in kernel_family:   # noU: the smoothed field is not stored (its `1` node recomputes it)
+        return (8.0 if "noU" in kernel_family else 16.0) * n + 8.0 * (N // 2) ** 2
+    if "prolong" in kernel_family:    # pre3: the pre-smoothed field is recomputed (3 sweeps from zero), not read
+        return (16.0 if "pre" in kernel_family else 24.0) * n + 8.0 * (N // 2) ** 2
     if "jacobi_stream" in kernel_family or "jacobi_pair" in kernel_family:
         return (16.0 if "zero" in kernel_family else 24.0) * n
     return None
@@ -318,6 +322,10 @@ def main():
                 "frac": round(k0["compulsory_GBs"] / HBM_PEAK_GBS, 4), "compulsory_bytes": cb,
                 "traffic": measured_traffic(k0["kernel"]) if not args.mixed else None,
                 "avg_ms": k0["avg_ms"], "launches": k0["launches"],
+                **({"note": "fused `1` node that RECOMPUTES the level's pre-smoothed field (3 sweeps from zero) instead of reading it: "
+                            "8 B/pt less to read here, 8 B/pt less to write in the `-1` node, twice the arithmetic -- the launch is "
+                            "co-limited by VALU issue, so its byte rate is below the 0.60-0.62 of the store/re-read form while "
+                            "the cycle is 15 % faster (DESIGN 3.1)"} if "pre3" in k0["kernel"] else {}),
                 "algorithmic_equiv": {"bytes": next(e["algo_bytes"] for e in prof if e["name"] == k0["kernel"]),
                                       "GBs": k0["algorithmic_equiv_GBs"],
                                       "note": "SURVEY 8d bytes (one HBM pass per sweep) / launch time; > peak because S sweeps share one pass"}}

@@ -233,6 +233,8 @@ struct Fusion {
     double *Fc = nullptr;
     int M = 0;
     const RestrictTable *rt = nullptr;
+    int pre = 0;          // `1` node: recompute the pre-smoothed field (pre sweeps from zero) instead of reading U_in
+    bool no_out = false;  // `-1` node: do not store the smoothed field
 };
 
 void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, int step, double *error_dev,
@@ -289,14 +291,15 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
             // + 8m + 16n for a folded prolongation+addition; the fused error costs nothing
             const bool pro = (i == 0 && fu.coarse), res = last && (D_out || fu.Fc), rst = last && fu.Fc;
             char name[40];
-            snprintf(name, sizeof name, "jacobi_stream<%d%s%s%s%s>", take, src ? "" : ",zero", pro ? ",prolong" : "",
-                     res ? ",res" : "", rst ? ",restrict" : "");
-            double bytes = (double)n * (24.0 * take + (src ? 0.0 : 8.0) + (res ? 24.0 : 0.0));
+            snprintf(name, sizeof name, "jacobi_stream<%d%s%s%s%s%s%s>", take, (src || fu.pre) ? "" : ",zero", pro ? ",prolong" : "",
+                     res ? ",res" : "", rst ? ",restrict" : "", fu.no_out ? ",noU" : "", fu.pre ? ",pre3" : "");
+            double bytes = (double)n * (24.0 * (take + fu.pre) + ((src || fu.pre) ? 0.0 : 8.0) + (res ? 24.0 : 0.0));
             if (rst) bytes += 8.0 * n + 8.0 * fu.M * fu.M;
             if (pro) bytes += 16.0 * n + 8.0 * fu.Nc * fu.Nc;
             ProfScope ps(name, N, bytes);
             k::jacobi_stream(s, N, dx2, inv, src, F, dst, take, last ? error_dev : nullptr, last ? D_out : nullptr,
-                             d_sign, pro ? fu.coarse : nullptr, fu.Nc, fu.pt, rst ? fu.Fc : nullptr, fu.M, fu.rt);
+                             d_sign, pro ? fu.coarse : nullptr, fu.Nc, fu.pt, rst ? fu.Fc : nullptr, fu.M, fu.rt, nullptr, nullptr, nullptr,
+                             fu.pre, fu.no_out);
         } else {
             // (k_jacobi_pair on even N, k_jacobi_simple on odd N: the launcher picks)
             ProfScope ps(src ? (N % 2 == 0 && N >= 512 ? "jacobi_pair" : "jacobi_simple") : "jacobi_simple<zero>", N, (double)n * (src ? 24.0 : 32.0));
@@ -319,6 +322,44 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
 }
 
 }  // namespace
+
+bool recompute_available(int Nc, int N, int pre, int step)
+{
+    static const int min_n = [] { const char *e = getenv("MG_RECOMPUTE_MIN_N"); return e ? atoi(e) : 4096; }();  // (measured: 2048 loses 4 us per level, 4096 gains 35, 8192 gains 130)
+    if (pre != 3 || step != 3 || N < min_n || ctx().smoother == SMOOTHER_SIMPLE || !k::stream_fusable(N)) return false;
+    const ProlongTable &pt = prolong_table(Nc, N);
+    return pt.owner_row && pt.fusable;
+}
+
+void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c)
+{
+    const RestrictTable &rt = restrict_table(N, M);
+    if (!rt.lo || !rt.fusable || !k::stream_fusable(N) || step < 1 || step > k::stream_max_steps()) {
+        fail(MG_ERR_UNSUPPORTED, "smooth_restrict_no_out: N=%d M=%d step=%d is not a fused `-1` node", N, M, step);
+        return;
+    }
+    Fusion fu;
+    fu.Fc = F_c;
+    fu.M = M;
+    fu.rt = &rt;
+    fu.no_out = true;
+    smooth_pp(N, L, nullptr, U_unused, F, step, error_dev, nullptr, -1, fu);
+}
+
+void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double *U_out, double *F, int pre, int step, double *error_dev)
+{
+    if (!recompute_available(Nc, N, pre, step)) {
+        fail(MG_ERR_UNSUPPORTED, "prolong_smooth_recompute: Nc=%d N=%d pre=%d step=%d", Nc, N, pre, step);
+        return;
+    }
+    Fusion fu;
+    fu.coarse = U_c;
+    fu.Nc = Nc;
+    fu.pt = &prolong_table(Nc, N);
+    fu.pre = pre;
+    smooth_pp(N, L, nullptr, U_out, F, step, error_dev, nullptr, +1, fu);
+}
+
 }  // namespace mg
 
 using namespace mg;

@@ -32,6 +32,9 @@ struct LevelNode {  // src/linkedlist.h:4-30
     LevelNode *nextNode = nullptr, *prevNode = nullptr;
     int step = 0;
     double smoothingError = 0.0;
+    // > 0: U holds nothing yet -- it is `pending_pre` Jacobi sweeps from zero on this F, which the fused `-1` node did
+    // not store (smooth_restrict_no_out); the fused `1` node recomputes it in flight, anyone else calls ensure_U first
+    int pending_pre = 0;
 };
 
 class LevelList {
@@ -342,6 +345,15 @@ int trigger_smoothing(Exec &x, LevelNode *lv)
     return lv->step;
 }
 
+// materialise a pre-smoothed field that its `-1` node left to be recomputed (the rare consumer that is not the fused
+// `1` node: a 0-step `1` node, a file that ends on the way down)
+void ensure_U(mg_cycle_plan *p, LevelNode *lv)
+{
+    if (!lv || lv->pending_pre <= 0) return;
+    mg_smooth_pp(lv->N, p->L, nullptr, lv->U, lv->F, lv->pending_pre, nullptr, nullptr, -1);
+    lv->pending_pre = 0;
+}
+
 // fixed-step smoothing of the last level, result in lv->U.  zero_start: the driver's
 // memset(U,0) (:256) is folded into the first sweep.  want_D: also produce -residual in
 // lv->D (getResidual :268 and the sign flip :277-280 folded into the last sweep).
@@ -541,7 +553,13 @@ void run_nodes(Exec &x)
                 cycle.Push_back(next_N);  // :283
                 if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
                 double *Fc = cycle.last()->F;
-                if (!keep) {
+                lv->pending_pre = 0;
+                if (!keep && p->con_step > 0 && recompute_available(next_N, lv->N, step, p->con_step)) {
+                    // the `1` node of this level will redo these sweeps in its own pipeline: U is neither written now
+                    // nor read then
+                    smooth_restrict_no_out(lv->N, p->L, lv->U, lv->F, step, error_slot(p, rec), next_N, Fc);
+                    lv->pending_pre = step;
+                } else if (!keep) {
                     mg_smooth_restrict(lv->N, p->L, nullptr, lv->U, lv->F, step, error_slot(p, rec), next_N, Fc);
                 } else {
                     double *tmp = (double *)p->pool.get((size_t)lv->N * lv->N * sizeof(double));
@@ -613,6 +631,17 @@ void run_nodes(Exec &x)
                 report_smoothing(p, rec);
                 continue;
             }
+            ensure_U(p, coarse);
+            if (fused && step > 0 && fine->pending_pre > 0 && recompute_available(coarse->N, fine->N, fine->pending_pre, step)) {
+                const int rec = add_record(p, 1, fine->N, step);
+                prolong_smooth_recompute(coarse->N, coarse->U, fine->N, p->L, fine->U, fine->F, fine->pending_pre, step, error_slot(p, rec));
+                fine->pending_pre = 0;
+                cycle.Remove_back();  // :363
+                report_text(p, arrow);
+                report_smoothing(p, rec);
+                continue;
+            }
+            ensure_U(p, fine);
             if (fused && step > 0) {
                 // tempU (:353), doProlongation (:354), doGridAddition (:368) and the post-smoothing
                 // (:416) in one pass; the fine level's D is dead here and receives the result
@@ -825,6 +854,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         c.active_pool = nullptr;
         p->warm_runs++;
         LevelNode *last = p->levels->last();
+        ensure_U(p, last);
         p->final_U = last->U;
         p->final_N = last->N;
         if (mixed && status == 0 && last->N == p->N_max) {

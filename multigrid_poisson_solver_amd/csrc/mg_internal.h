@@ -210,7 +210,10 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
                    double *out, int steps, double *err_out, double *D_out, int d_sign,
                    const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
                    const RestrictTable *rt, const RowWindow *fine_w = nullptr,
-                   const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr);
+                   const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr,
+                   // pre > 0 (fused `1` node): `in` is not read, it is recomputed as `pre` sweeps from zero on F;
+                   // no_out (fused `-1` node): the smoothed field is not stored (its `1` node will recompute it)
+                   int pre = 0, bool no_out = false);
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);
@@ -281,6 +284,13 @@ void gauss_seidel_blocks_launch(hipStream_t s, int N, double h2, double inv, dou
 int  gs_single_workgroup_max_n();
 }  // namespace k
 
+// The pre-smoothed U of a level is dead weight between its `-1` and its `1` node: 8 B per point written, 8 B read.  When
+// recompute_available(), the `-1` node (zero start) may run with smooth_restrict_no_out() and the `1` node with
+// prolong_smooth_recompute(), which redoes the `pre` sweeps from zero on the same F inside its own pipeline: the same
+// expressions, the same bits, two array passes less.
+bool recompute_available(int Nc, int N, int pre, int step);
+void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c);
+void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double *U_out, double *F, int pre, int step, double *error_dev);
 // mg_prolong_smooth_f32 whose result goes to an fp64 array (exact widening in the store) instead of U_out
 void prolong_smooth_f32_wide(int Nc, const float *U_c, int N, double L, const float *U_in, double *U_out_wide, const float *F,
                              int step, double *error_dev);

@@ -44,6 +44,9 @@
 // MG_REAL = double every expression is exactly what it was before the split.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -104,6 +107,8 @@ struct StreamParams {
     int coarse_base, coarse_rows;   // IN_PROLONG: window of the coarse array
     int raw_norm;                   // error output is the raw sum over the owned rows
     int nt_min_n;                   // fused `1` nodes of grids at least this large store U non-temporally
+    int no_out;                     // the smoothed U is not stored (a `-1` node whose `1` node recomputes it: PRE)
+    int pre;                        // fused `1` node: sweeps from zero to recompute instead of reading `in`
     int fc_base, fc_rows;           // RESTRICT: window of Fc (global row of its first local row, rows)
     // IN_PROLONG: coarse grid and the host-built tables of doProlongation
     const real_t *coarse;
@@ -176,6 +181,9 @@ struct Row {
 // walk costs two scalar additions instead of 64-bit vector arithmetic per lane.
 // (the lane offset is in BYTES: `uniform pointer + zero-extended 32-bit value` is the shape the instruction selector
 // needs; an element index would have to be scaled in 64 bits first)
+#ifndef MG_ZERO_LEVEL1
+#define MG_ZERO_LEVEL1 1   // 0: the first sweep from zero through the general expression (A/B switch)
+#endif
 #ifndef MG_NT_LOADS
 #define MG_NT_LOADS 0   // experiment: 1 = F rows, 2 = U and F rows loaded non-temporally
 #endif
@@ -293,16 +301,30 @@ __device__ __forceinline__ CoarseV<NCV> load_coarse_local(const real_t *__restri
     return c;
 }
 
-template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false>
+// f(integral_constant<int, 0>), f(<1>), ... while f returns true
+template <class F, int... K>
+__device__ __forceinline__ void unrolled_while(F &&f, std::integer_sequence<int, K...>)
+{
+    (void)(f(std::integral_constant<int, K>{}) && ...);
+}
+
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false, int PRE = 0>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || COLS == 4 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
     static_assert(COLS != 4 || sizeof(real_t) == 4, "4 columns per lane = one 16-byte access: fp32 fields only");
     constexpr int NCV = COLS / 2 + 2;  // coarse values a lane needs of one coarse row
     constexpr int NS = COLS >= 2 ? COLS / 2 : 1;  // coarse columns a lane can produce (one per column pair)
-    static_assert(PF + S + 2 <= 8 && PF < 4, "the F ring has 8 slots, the U ring 4");
+    // PRE > 0 (fused `1` node only): the level's pre-smoothed U is NOT read -- the matching `-1` node did not store it --
+    // but recomputed: PRE sweeps from the zero field on the same F (levels 1..PRE, the very expressions of the `-1`
+    // node), the prolongation is added to level PRE, S more sweeps follow (levels PRE+1..L).  8 B per point less to
+    // read here, 8 B per point less to write there, for PRE more sweeps of arithmetic in a kernel that waits for memory.
+    static_assert(PRE == 0 || (IN == IN_PROLONG && !RESTRICT), "recomputed pre-smoothing belongs to the fused `1` node");
+    constexpr int L = S + PRE;                         // levels of the pipeline
+    constexpr int NB = PF + L + 2 <= 8 ? 8 : 16;       // slots of the F ring = row steps of the loop body
+    static_assert(PF + L + 2 <= NB && PF < 4, "the F ring has NB slots, the U ring 4");
     constexpr int W = 64 * COLS;
-    constexpr int H = Halo<S, RESTRICT, COLS>::value;
+    constexpr int H = Halo<L, RESTRICT, COLS>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
 
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous
@@ -458,8 +480,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 #pragma unroll
     for (int j = 0; j < COLS; ++j) ms[j] = col_edge[j] ? real_t(0.0) : (p.d_sign < 0 ? real_t(-1.0) : real_t(1.0));
 
-    const int y_first = y0 - (S + 1);                             // first input row
-    const int T = (y1 - y0) + 2 * (S + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
+    const int y_first = y0 - (L + 1);                             // first input row
+    const int T = (y1 - y0) + 2 * (L + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
     const int y_end = y_first + T;                                // one past the last input row
 
     // ---- wave-uniform per-row table entries: ONE REGISTER PER TABLE, one row per lane.  Lane L of a block holds the
@@ -498,16 +520,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
         tbn_rc = ok ? v : -1;
         tbn_rw = w;
     };
+    // the prolongation lands on row (input row - PRE): its tables (and the coarse rows that travel with the F rows) are
+    // those of that row
+    const int yp_first = y_first - PRE;
     if constexpr (IN == IN_PROLONG) {
-        load_own_block(y_first);
+        load_own_block(yp_first);
         tb_own = tbn_own;
         tb_crow = tbn_crow;
-        load_weight_block(y_first);
+        load_weight_block(yp_first);
         tb_yh = tbn_yh;
         tb_yl = tbn_yl;
     }
     if constexpr (RESTRICT) {
-        load_restrict_block(y_first - (S + 2));
+        load_restrict_block(y_first - (L + 2));
         tb_rc = tbn_rc;
         tb_rw = tbn_rw;
     }
@@ -516,12 +541,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     // t - PF, read by level l at step t + l, by the residual at step t + S + 1); U rows in a ring of 2*PF.  The loop
     // body covers 8 steps, a multiple of every ring, so every slot index is a compile-time constant and nothing is
     // ever copied from slot to slot; a load never targets a register whose old value is still live.
-    Row<COLS> older[S + 1], newer[S + 1];
+    Row<COLS> older[L + 1], newer[L + 1];
 #pragma unroll
-    for (int l = 0; l <= S; ++l)
+    for (int l = 0; l <= L; ++l)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
-    constexpr int NB = 8, NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
+    constexpr int NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
     Row<COLS> fr[NB], pu[NU];
     CoarseV<NCV> pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
     int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
@@ -545,12 +570,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     const int yc_first = y_first < av_lo ? av_lo : (y_first < av_hi ? y_first : av_hi - 1);
     unsigned long long ld_off = (unsigned long long)(yc_first - p.row_base) * row_bytes;  // row of the next load
     int ld_t = 0;                                                                          // its step index (row y_first + ld_t)
-    long long st_off = (long long)(y_first - S - p.row_base) * (long long)row_bytes;       // row yin - S of the current step
+    long long st_off = (long long)(y_first - L - p.row_base) * (long long)row_bytes;       // row yin - L of the current step
     const unsigned inner_rows = (unsigned)(av_hi - av_lo - 1);
 
     // issue the loads of input row y_first + ld_t into their ring slots (u8 = ld_t % 8, compile-time at every call)
     auto fetch = [&](int u8) {
-        if constexpr (IN != IN_ZERO) pu[u8 % NU] = load_row<COLS, (MG_NT_LOADS >= 2)>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
+        if constexpr (IN != IN_ZERO && PRE == 0) pu[u8 % NU] = load_row<COLS, (MG_NT_LOADS >= 2)>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
         fr[u8] = load_row<COLS, (MG_NT_LOADS >= 1)>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
         if constexpr (IN == IN_PROLONG) {
             // the UPPER coarse row of this input row travels with it, so every vector load of the loop is issued at
@@ -567,7 +592,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 
     if constexpr (IN == IN_PROLONG) {
         // before the first rotation hB must belong to the owner row of the first input row
-        const int ys = y_first > av_lo ? y_first : av_lo;
+        const int ys = yp_first > av_lo ? yp_first : av_lo;
         if (ys < av_hi && ys < y_end) {
             const int i0 = table_i(p.p_orow, ys);
             const CoarseV<NCV> c0 = load_coarse<NCV>(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
@@ -585,7 +610,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     // the body once the parity of the chunk's first residual row is folded into the masks
     int nm_k0[COLS], nm_k1[COLS];  // masks of the residual rows at even / odd positions k
     {
-        const bool first_odd = ((y_first - S - 1) & 1) != 0;
+        const bool first_odd = ((y_first - L - 1) & 1) != 0;
 #pragma unroll
         for (int j = 0; j < COLS; ++j) {
             nm_k0[j] = first_odd ? nm_odd[j] : nm_even[j];
@@ -596,12 +621,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     for (int t0 = 0; t0 < T; t0 += NB) {
         // table blocks: (t0 & 63) == 56 -> load the blocks that start 8 steps from now; == 0 -> they take over.
         // The owner block runs PF steps ahead of the others (it serves the prefetch), so it switches inside the body.
-        if ((t0 & 63) == 56) {
+        if ((t0 & 63) == 64 - NB) {
             if constexpr (IN == IN_PROLONG) {
-                load_own_block(y_first + t0 + 8);
-                load_weight_block(y_first + t0 + 8);
+                load_own_block(yp_first + t0 + NB);
+                load_weight_block(yp_first + t0 + NB);
             }
-            if constexpr (RESTRICT) load_restrict_block(y_first + t0 + 8 - (S + 2));
+            if constexpr (RESTRICT) load_restrict_block(y_first + t0 + NB - (L + 2));
         }
         if ((t0 & 63) == 0 && t0 > 0) {
             if constexpr (IN == IN_PROLONG) {
@@ -613,13 +638,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 tb_rw = tbn_rw;
             }
         }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
+        // (the NB steps as calls with a compile-time k: `#pragma unroll` gives up on a body of this size at NB = 16, and a
+        // rolled loop would index the rings at run time, i.e. move them to scratch memory)
+        auto row_step = [&](auto k_tag) -> bool {
+            constexpr int k = decltype(k_tag)::value;
             const int t = t0 + k;
-            if (k > 0 && t >= T) break;  // (small levels: a chunk is a dozen rows, not a multiple of 8)
+            if (k > 0 && t >= T) return false;  // (small levels: a chunk is a dozen rows, not a multiple of 8)
             const int yin = y_first + t;
             Row<COLS> nw;
-            if constexpr (IN == IN_ZERO) {
+            if constexpr (IN == IN_ZERO || PRE > 0) {
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) nw.v[j] = 0.0;
             } else {
@@ -629,16 +656,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             const CoarseV<NCV> own_up = pc[k % NU];
             if constexpr (IN == IN_PROLONG) {
                 // the prefetch below reads the owner of row t + PF: from step 64 m - PF on that is the next block
-                if (k == NB - PF && (t0 & 63) == 56) {
+                if (k == NB - PF && (t0 & 63) == 64 - NB) {
                     tb_own = tbn_own;
                     tb_crow = tbn_crow;
                 }
             }
             fetch((k + PF) % NB);  // the row PF ahead, into the slots whose rows were retired (k + PF - 8 resp. k - PF)
 
-            if constexpr (IN == IN_PROLONG) {
-                // level 0 = U + P(coarse): doProlongation :700 as a gather, then
-                // doGridAddition :569 (U1 = U1 + U2).  own_i is wave-uniform.
+            // U + P(coarse): doProlongation :700 as a gather, then doGridAddition :569 (U1 = U1 + U2), on the row the
+            // prolongation belongs to -- the input row (PRE == 0) or level PRE's row yin - PRE.  own_i is wave-uniform.
+            auto add_prolongation = [&](Row<COLS> &row) {
                 if (own_i >= 0) {
                     if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
 #pragma unroll
@@ -652,14 +679,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     for (int j = 0; j < COLS; ++j) {
                         const real_t num = hA[j] * own_yh + hB[j] * own_yl;
                         const real_t pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
-                        nw.v[j] = nw.v[j] + pv;
+                        row.v[j] = row.v[j] + pv;
                     }
                 }
-            }
+            };
+            if constexpr (IN == IN_PROLONG && PRE == 0) add_prolongation(nw);
 
-            // levels 1..S: level l produces row yin-l from level l-1 rows yin-l-1, yin-l, yin-l+1
+            // levels 1..L: level l produces row yin-l from level l-1 rows yin-l-1, yin-l, yin-l+1
 #pragma unroll
-            for (int l = 1; l <= S; ++l) {
+            for (int l = 1; l <= L; ++l) {
                 const int y = yin - l;
                 const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;  // 0 on the rim rows 0 and N-1
                 const Row<COLS> c = newer[l - 1], so = older[l - 1];
@@ -667,6 +695,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> o;
+                if constexpr ((IN == IN_ZERO || PRE > 0) && MG_ZERO_LEVEL1) {
+                    if (l == 1) {
+                        // the first sweep from the zero field: every neighbour and the point itself are +0, so the sum,
+                        // `- 4*U` and `U +` of the general expression below are exact no-ops -- the same bits without them
+#pragma unroll
+                        for (int j = 0; j < COLS; ++j) {
+                            const real_t t4 = real_t(0.0) - dx2 * f.v[j];
+                            o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), t4, real_t(0.0));
+                        }
+                        older[l - 1] = c;
+                        newer[l - 1] = nw;
+                        nw = o;
+                        if constexpr (IN == IN_PROLONG && PRE > 0) {
+                            if (l == PRE) add_prolongation(nw);
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < COLS; ++j) {
                     const real_t w = j == 0 ? west0 : c.v[j > 0 ? j - 1 : 0];
@@ -682,12 +728,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                 older[l - 1] = c;
                 newer[l - 1] = nw;
                 nw = o;
+                if constexpr (IN == IN_PROLONG && PRE > 0) {
+                    if (l == PRE) add_prolongation(nw);  // nw: the pre-smoothed row yin - PRE, as the `-1` node had it
+                }
             }
 
-            // nw is level S of row yin-S: the smoothed U
+            // nw is level L of row yin-L: the smoothed U
             {
-                const int y = yin - S;
-                if ((unsigned)(y - y0) < rows_own && lane_owns) {
+                const int y = yin - L;
+                if ((unsigned)(y - y0) < rows_own && lane_owns && !p.no_out) {
                     if (sizeof(real_t) != sizeof(double) && p.out_wide) {
                         // mixed precision: the last node of a cycle hands its result over in fp64 (exact
                         // widening) instead of leaving it to a separate conversion pass
@@ -716,12 +765,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 
             // residual stage, row yin-S-1 (src/MG_solver_CPU.cpp:560 and the error sums :611)
             if (want_res) {
-                const int y = yin - S - 1;
+                const int y = yin - L - 1;
                 const bool mine_row = (unsigned)(y - y0) < rows_own;  // each point counted once
                 const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;
                 const int cm = (mine_row && (unsigned)(y - p.norm_y0) < rows_norm) ? inner : 0;  // -1: the row counts
-                const Row<COLS> c = newer[S], so = older[S];
-                const Row<COLS> &f = fr[(k - S - 1 + NB) % NB];
+                const Row<COLS> c = newer[L], so = older[L];
+                const Row<COLS> &f = fr[(k - L - 1 + NB) % NB];
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> d;
@@ -772,10 +821,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     d_prev = d;
                 }
             }
-            older[S] = newer[S];
-            newer[S] = nw;
+            older[L] = newer[L];
+            newer[L] = nw;
             st_off += row_bytes;
-        }
+            return true;
+        };
+        unrolled_while(row_step, std::make_integer_sequence<int, NB>{});
     }
 #ifdef MG_STREAM_TRACE
     if (p.trace && (threadIdx.x & 63) == 0) {  // per wave: start, end of prologue, end of loop (100 MHz ticks); [0..3]: legacy record of the middle tile
@@ -803,13 +854,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
 // this instantiation x CUs) where the grid is large enough, never fewer than 8 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
-template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false>
+template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false, int PRE = 0>
 void launch_k(hipStream_t s, StreamParams p, double *err_out)
 {
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT, PRE>, 64 * WAVES_PER_WG, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 2;
         }
@@ -818,7 +869,7 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int N = p.N;
     const int own = p.own_y1 - p.own_y0;  // rows this launch updates (N on a single GPU)
     if (own <= 0) return;
-    constexpr int OW = 64 * COLS - 2 * Halo<S, RESTRICT, COLS>::value;
+    constexpr int OW = 64 * COLS - 2 * Halo<S + PRE, RESTRICT, COLS>::value;
     const int strips = (N + OW - 1) / OW;
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     static const int resident_pct = [] { const char *e = getenv("MG_RESIDENT_PCT"); return e ? atoi(e) : 100; }();
@@ -850,7 +901,7 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         if (!p.part) return;
     }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT, PRE>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
 #ifdef MG_STREAM_TRACE
     {
         long long t[4];
@@ -925,6 +976,13 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
+        if constexpr (S == 3 && PF == 2 && sizeof(real_t) == 8) {
+            if (p.pre == 3) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
+                if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true, 3>(s, p, err_out);
+                else launch_k<S, 2, IN_PROLONG, false, PF, false, 3>(s, p, err_out);
+                return;
+            }
+        }
         if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true>(s, p, err_out);
         else launch_k<S, 2, IN_PROLONG, false, PF>(s, p, err_out);
     } else {
@@ -952,8 +1010,12 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps,
                 double *err_out, real_t *D_out, int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M,
                 const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
-                double *out_wide = nullptr)
+                double *out_wide = nullptr, int pre = 0, bool no_out = false)
 {
+    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc && !fine_w && !out_wide && sizeof(real_t) == 8)) {
+        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused fp64 `1` node on a whole grid (pre=%d steps=%d)", pre, steps);
+        return;
+    }
     if (steps < 1 || steps > MAX_S) {
         fail(MG_ERR_ARG, "jacobi_stream: %d sweeps per launch (1..%d)", steps, MAX_S);
         return;
@@ -970,6 +1032,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.F = F;
     p.out = out;
     p.out_wide = out_wide;
+    p.pre = pre;
+    p.no_out = no_out ? 1 : 0;
     p.D = D_out;
     p.d_sign = d_sign;
     p.row_base = fine_w ? fine_w->base : 0;

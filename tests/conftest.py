@@ -25,6 +25,9 @@ os.environ.setdefault("MG_SLAB_POISON", "1")
 os.environ.setdefault("MG_F32_COLS4_MIN_N", "1024")
 # likewise the instantiation of the fused `1` node with non-temporal stores (the product: N >= 8192)
 os.environ.setdefault("MG_NT_MIN_N", "1024")
+# and the fused node pair that recomputes the pre-smoothed field instead of storing and re-reading it (the product:
+# N >= 4096): from N = 256 on, so that the cycle tests against the oracle run through it at every size they use
+os.environ.setdefault("MG_RECOMPUTE_MIN_N", "256")
 
 
 def pytest_configure(config):
