@@ -325,7 +325,12 @@ def main():
                 **({"note": "fused `1` node that RECOMPUTES the level's pre-smoothed field (3 sweeps from zero) instead of reading it: "
                             "8 B/pt less to read here, 8 B/pt less to write in the `-1` node, twice the arithmetic -- the launch is "
                             "co-limited by VALU issue, so its byte rate is below the 0.60-0.62 of the store/re-read form while "
-                            "the cycle is 15 % faster (DESIGN 3.1)"} if "pre3" in k0["kernel"] else {}),
+                            "the cycle is 15 % faster (DESIGN 3.1)",
+                    # the same launch priced at the bytes of the form it replaces (U read as well: 24 n + 8 m)
+                    "store_reread_equiv": {"bytes": (24.0 * N * N + 8.0 * (N // 2) ** 2) * elem,
+                                           "GBs": round((24.0 * N * N + 8.0 * (N // 2) ** 2) * elem / (k0["avg_ms"] * 1e-3) / 1e9, 1),
+                                           "frac": round((24.0 * N * N + 8.0 * (N // 2) ** 2) * elem / (k0["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                   if "pre3" in k0["kernel"] else {}),
                 "algorithmic_equiv": {"bytes": next(e["algo_bytes"] for e in prof if e["name"] == k0["kernel"]),
                                       "GBs": k0["algorithmic_equiv_GBs"],
                                       "note": "SURVEY 8d bytes (one HBM pass per sweep) / launch time; > peak because S sweeps share one pass"}}
