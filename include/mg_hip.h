@@ -278,6 +278,11 @@ int  mg_slab_ghost_rows(void);
  * [lo, hi) pairs.  Returns the number of levels, -1 when a halo would not fit the neighbouring slab. */
 int  mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int steps, int ca_mode, int ca_pct,
                       int *level_out, int *rank_out);
+/* host-only: pre_out[l] > 0 = on level l (only distributed levels matter) the `-1` launch does not store the smoothed
+ * U and the `1` launch recomputes it, pre_out[l] sweeps from zero on F, instead of reading it (fp64 plans, levels of
+ * at least MG_RECOMPUTE_MIN_N = 4096 points per side; MG_SLAB_RECOMPUTE=0 switches it off): such a level has no U
+ * halo.  Returns the number of levels. */
+int  mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out);
 
 typedef struct mg_slab_plan mg_slab_plan;
 /* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:

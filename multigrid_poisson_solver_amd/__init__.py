@@ -85,6 +85,7 @@ ABI = {
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
     "mg_slab_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mg_slab_recompute_levels": (_i, [_i, _i, _i, _vp]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
@@ -560,8 +561,9 @@ def slab_partition(N_max, N_min, nranks, collapse_N):
 
 
 def slab_schedule(N_max, N_min, nranks, collapse_N, steps, ca_mode=-1, ca_pct=-1):
-    """mg_slab_schedule (host-only): per level a dict N, collapsed, halo, needF, xF, xU and, per rank, the row
-    ranges own / dext / ext / fwr as (lo, hi) tuples."""
+    """mg_slab_schedule (host-only): per level a dict N, collapsed, halo, needF, xF, xU, pre (> 0: the level's `1`
+    launch recomputes the pre-smoothed field, its `-1` launch does not store it) and, per rank, the row ranges
+    own / dext / ext / fwr as (lo, hi) tuples."""
     lib_ = load_library()
     nl = lib_.mg_slab_partition(N_max, N_min, nranks, collapse_N, None, None)
     lev = np.zeros((nl, 6), dtype=np.int32)
@@ -570,10 +572,12 @@ def slab_schedule(N_max, N_min, nranks, collapse_N, steps, ca_mode=-1, ca_pct=-1
     if n < 0:
         lib_.mg_clear_error()
         raise MGError("mg_slab_schedule: a halo does not fit the neighbouring slab (raise collapse_N)")
+    pre = np.zeros(nl, dtype=np.int32)
+    lib_.mg_slab_recompute_levels(N_max, N_min, steps, pre.ctypes.data)
     out = []
     for l in range(nl):
         d = dict(N=int(lev[l, 0]), collapsed=bool(lev[l, 1]), halo=int(lev[l, 2]), needF=int(lev[l, 3]), xF=int(lev[l, 4]),
-                 xU=int(lev[l, 5]))
+                 xU=int(lev[l, 5]), pre=0 if lev[l, 1] else int(pre[l]))
         for k, name in enumerate(("own", "dext", "ext", "fwr")):
             d[name] = [(int(rk[l, r, 2 * k]), int(rk[l, r, 2 * k + 1])) for r in range(nranks)]
         out.append(d)

@@ -323,9 +323,15 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
 
 }  // namespace
 
-bool recompute_available(int Nc, int N, int pre, int step)
+int recompute_min_n()
 {
     static const int min_n = [] { const char *e = getenv("MG_RECOMPUTE_MIN_N"); return e ? atoi(e) : 4096; }();  // (measured: 2048 loses 4 us per level, 4096 gains 35, 8192 gains 130)
+    return min_n;
+}
+
+bool recompute_available(int Nc, int N, int pre, int step)
+{
+    const int min_n = recompute_min_n();
     if (pre != 3 || step != 3 || N < min_n || ctx().smoother == SMOOTHER_SIMPLE || !k::stream_fusable(N)) return false;
     const ProlongTable &pt = prolong_table(Nc, N);
     return pt.owner_row && pt.fusable;
@@ -696,11 +702,11 @@ void slab_smooth(int N, double L, const double *U_in, double *U_out, const doubl
     if (sf.Fc) bytes += 8.0 * n + 2.0 * n;
     if (sf.coarse) bytes += 16.0 * n + 2.0 * n;
     char name[40];
-    snprintf(name, sizeof name, "slab_stream<%d%s%s%s>", step, U_in ? "" : ",zero", sf.coarse ? ",prolong" : "",
-             sf.Fc ? ",res,restrict" : "");
+    snprintf(name, sizeof name, "slab_stream<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
+             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", sf.pre ? ",pre3" : "");
     ProfScope ps(name, N, bytes);
     k::jacobi_stream(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, nullptr, -1, sf.coarse, sf.Nc, pt, sf.Fc,
-                     sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
+                     sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr, sf.pre, sf.no_out);
 }
 
 void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const float *F, int step, double *raw_norm_out,

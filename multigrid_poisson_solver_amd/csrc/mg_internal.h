@@ -157,6 +157,8 @@ struct SlabFusion {
     double *Fc = nullptr;
     int M = 0;
     RowWindow fine_w, coarse_w, fc_w;
+    int pre = 0;          // `1` launch: the pre-smoothed field is recomputed (pre sweeps from zero), U_in is not read
+    bool no_out = false;  // `-1` launch: the smoothed field is not stored
 };
 void slab_smooth(int N, double L, const double *U_in, double *U_out, const double *F, int step, double *raw_norm_out,
                  const SlabFusion &sf);
@@ -289,6 +291,7 @@ int  gs_single_workgroup_max_n();
 // prolong_smooth_recompute(), which redoes the `pre` sweeps from zero on the same F inside its own pipeline: the same
 // expressions, the same bits, two array passes less.
 bool recompute_available(int Nc, int N, int pre, int step);
+int  recompute_min_n();   // MG_RECOMPUTE_MIN_N (default 4096)
 void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c);
 void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double *U_out, double *F, int pre, int step, double *error_dev);
 // mg_prolong_smooth_f32 whose result goes to an fp64 array (exact widening in the store) instead of U_out

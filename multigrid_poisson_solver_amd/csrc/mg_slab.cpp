@@ -74,6 +74,7 @@ struct LevelPlan {
     int needF = 0;           // rows of F beyond the owned rows that the level's launches read
     int xF = 0;              // > 0: that many rows of this level's F are exchanged after the finer level's `-1` launch
     int xU = 0;              // > 0: that many rows of this level's U are exchanged after its own `-1` launch
+    int pre = 0;             // > 0: the level's `-1` launch does not store U, its `1` launch recomputes it (pre sweeps from zero on F)
 };
 
 struct Partition {
@@ -465,7 +466,9 @@ void run(mg_slab_plan *p)
                     // a collapsed next level is a full array on every rank: this rank writes its rows
                     sf.fc_w = nxt.collapsed ? RowWindow{0, M, cpart.lo[(size_t)r], cpart.hi[(size_t)r]} : window_of(nxt, r);
                     // U starts from zero on every descent (:252-257; a restart inside one file is
-                    // not supported in slab mode), so the launch reads no U at all
+                    // not supported in slab mode), so the launch reads no U at all -- nor does it store one where
+                    // the level's `1` launch recomputes it
+                    sf.no_out = plan_cur.pre > 0;
                     if (p->mixed)
                         slab_smooth_f32(cur.N, p->L, nullptr, (float *)cur.loc[i].U, (const float *)cur.loc[i].F, step,
                                         raw_slot(p, (size_t)rec, i), sf);
@@ -532,11 +535,13 @@ void run(mg_slab_plan *p)
                     sf.Nc = coarse.N;
                     sf.coarse = coarse.loc[i].U;
                     sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse, r);
+                    sf.pre = p->lp[hier].pre;
                     if (p->mixed)
                         slab_smooth_f32(fine.N, p->L, (const float *)fine.loc[i].U, (float *)fine.loc[i].D, (const float *)fine.loc[i].F,
                                         step, raw_slot(p, (size_t)rec, i), sf);
                     else
-                        slab_smooth(fine.N, p->L, fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
+                        slab_smooth(fine.N, p->L, sf.pre ? nullptr : fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step,
+                                    raw_slot(p, (size_t)rec, i), sf);
                     std::swap(fine.loc[i].U, fine.loc[i].D);
                 }
             }
@@ -566,15 +571,22 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 //              update them.
 // ca_mode: 0 = exchange every halo (one group per level, the round-1 schedule), 1 = recompute F halos (default),
 // 2 = recompute the U halos as well (no ghost exchange at all, only the collapse all-gather).
+// recompute_min: levels at least this large run the node pair that neither stores nor re-reads the pre-smoothed U
+// (0 = none: mixed-precision plans, MG_SLAB_RECOMPUTE=0): their `1` launch reads F on grow(ext, 2*steps + 2) and no
+// U at all, so such a level has no U halo to recompute or to exchange
 static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Partition> &parts, const std::vector<bool> &collapsed,
-                          int nranks, int steps, int ca_mode, int max_pct, std::vector<LevelPlan> *out)
+                          int nranks, int steps, int ca_mode, int max_pct, int recompute_min, std::vector<LevelPlan> *out)
 {
     const size_t nl = sizes.size();
     size_t nd = 0;
     while (nd < nl && !collapsed[nd]) ++nd;  // levels 0 .. nd-1 are distributed
     const int H = steps + 2;  // input rows a launch loads beyond the rows it updates (Halo<S> + 1 spare)
+    const int H2 = 2 * steps + 2;  // the same for the 2*steps levels of a recomputing `1` launch
     const size_t R = (size_t)nranks;
     std::vector<LevelPlan> lp(nl);
+    for (size_t l = 0; l < nd; ++l) lp[l].pre = (recompute_min > 0 && steps == 3 && sizes[l] >= recompute_min && sizes[l] % 2 == 0) ? steps : 0;
+    // F rows the launches of level `P` read: the `-1` launch around dext, the `1` launch around ext
+    auto f_rows = [&](const LevelPlan &P, size_t r, int n) { return unite(grow(P.dext[r], H, n), grow(P.ext[r], P.pre ? H2 : H, n)); };
     // owned rows and the rows of the way up, finest level first
     for (size_t l = 0; l < nd; ++l) {
         LevelPlan &P = lp[l];
@@ -609,7 +621,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
         int rows_min = 1 << 30;
         for (size_t r = 0; r < R; ++r) {
             P.dext[r] = P.own[r];
-            if (ca_mode >= 2) P.dext[r] = unite(P.dext[r], grow(P.ext[r], H, N));  // U halo of the way up recomputed as well
+            if (ca_mode >= 2 && !P.pre) P.dext[r] = unite(P.dext[r], grow(P.ext[r], H, N));  // U halo of the way up recomputed as well
             rows_min = std::min(rows_min, P.own[r].hi - P.own[r].lo);
         }
         if (l + 1 < nd) {
@@ -621,7 +633,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
             std::vector<Span> cand(R);
             int growth = 0, needF = 0;
             for (size_t r = 0; r < R; ++r) {
-                const Span need = grow(unite(C.dext[r], C.ext[r]), H, M);  // rows of the next level's F its launches read
+                const Span need = f_rows(C, r, M);  // rows of the next level's F its launches read
                 needF = std::max(needF, beyond(need, C.own[r]));
                 cand[r] = P.dext[r];
                 const int ra = std::max(1, need.lo), rb = std::min(M - 2, need.hi - 1);
@@ -654,7 +666,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
     if (nd > 0) {
         LevelPlan &T = lp[0];
         for (size_t r = 0; r < R; ++r) {
-            T.needF = std::max(T.needF, beyond(grow(unite(T.dext[r], T.ext[r]), H, sizes[0]), T.own[r]));
+            T.needF = std::max(T.needF, beyond(f_rows(T, r, sizes[0]), T.own[r]));
             T.fwr[r] = T.own[r];
         }
     }
@@ -666,7 +678,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
         for (size_t r = 0; r < R; ++r) {
             rows_min = std::min(rows_min, P.own[r].hi - P.own[r].lo);
             const Span needU = grow(P.ext[r], H, N);
-            if (!inside(needU, P.dext[r])) P.xU = std::max(P.xU, beyond(needU, P.own[r]));
+            if (!P.pre && !inside(needU, P.dext[r])) P.xU = std::max(P.xU, beyond(needU, P.own[r]));
             halo = std::max(halo, beyond(unite(P.dext[r], P.ext[r]), P.own[r]));
             halo = std::max(halo, beyond(P.fwr[r], P.own[r]));
         }
@@ -680,6 +692,13 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
     }
     *out = lp;
     return true;
+}
+
+// levels from this size on run the recomputing node pair (fp64 plans; MG_SLAB_RECOMPUTE=0 switches it off)
+static int slab_recompute_min(bool mixed)
+{
+    static const bool on = [] { const char *e = getenv("MG_SLAB_RECOMPUTE"); return !e || atoi(e) != 0; }();
+    return (mixed || !on || ctx().smoother == SMOOTHER_SIMPLE) ? 0 : recompute_min_n();
 }
 
 static int slab_ca_mode()
@@ -725,6 +744,17 @@ int mg_slab_partition(int N_max, int N_min, int nranks, int collapse_N, int *out
 
 int mg_slab_ghost_rows(void) { return MIN_HALF; }
 
+// host-only: pre_out[l] = sweeps the `1` launch of level l recomputes from zero instead of reading the level's U
+// (0: the level stores and re-reads it), for the fp64 plan mg_slab_load would build
+int mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out)
+{
+    int nl = 0;
+    const int min_n = slab_recompute_min(false);
+    for (int n = N_max; n >= N_min && n > 0; n /= 2, ++nl)
+        if (pre_out) pre_out[nl] = (min_n > 0 && steps == 3 && n >= min_n && n % 2 == 0) ? steps : 0;
+    return nl;
+}
+
 // host-only: the schedule mg_slab_load derives for a hierarchy (`steps` sweeps per node; ca_mode / ca_pct < 0: the
 // defaults resp. env MG_SLAB_CA / MG_SLAB_CA_PCT).  level_out[l*6 + ..] = {N, collapsed, halo, needF, xF, xU};
 // rank_out[(l*nranks + r)*8 + ..] = {own.lo, own.hi, dext.lo, dext.hi, ext.lo, ext.hi, fwr.lo, fwr.hi} (zeros for
@@ -748,7 +778,7 @@ int mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int steps
     }
     std::vector<LevelPlan> lp;
     if (!slab_schedule(sizes, parts, collapsed, nranks, steps, ca_mode < 0 ? slab_ca_mode() : ca_mode,
-                       ca_pct < 0 ? slab_ca_pct() : ca_pct, &lp))
+                       ca_pct < 0 ? slab_ca_pct() : ca_pct, slab_recompute_min(false), &lp))
         return -1;
     for (size_t l = 0; l < nl; ++l) {
         if (level_out) {
@@ -845,7 +875,7 @@ mg_slab_plan *mg_slab_load_flags(const char *path, int nranks, int rank, int col
         delete p;
         return nullptr;
     }
-    if (!slab_schedule(p->sizes, p->parts, p->level_collapsed, nranks, p->con_step, slab_ca_mode(), slab_ca_pct(), &p->lp)) {
+    if (!slab_schedule(p->sizes, p->parts, p->level_collapsed, nranks, p->con_step, slab_ca_mode(), slab_ca_pct(), slab_recompute_min(p->mixed), &p->lp)) {
         delete p;
         return nullptr;
     }

@@ -1012,8 +1012,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
                 const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
                 double *out_wide = nullptr, int pre = 0, bool no_out = false)
 {
-    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc && !fine_w && !out_wide && sizeof(real_t) == 8)) {
-        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused fp64 `1` node on a whole grid (pre=%d steps=%d)", pre, steps);
+    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc && !out_wide && sizeof(real_t) == 8)) {
+        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused fp64 `1` node (pre=%d steps=%d)", pre, steps);
         return;
     }
     if (steps < 1 || steps > MAX_S) {

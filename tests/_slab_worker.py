@@ -87,6 +87,9 @@ def main():
         Ul, _ = orc.doSmoothing(n, L, np.zeros((n, n)), F[l], step)
         assert not np.isnan(Ul[dext[0]:dext[1]]).any(), f"rank {rank}: NaN in the rows the -1 launch of level {n} updates"
         U[l] = keep_rows(Ul, dext)   # the launch writes exactly these rows of U ...
+        if sched[l]["pre"]:          # ... or none at all where the level's `1` launch recomputes the field from F
+            U[l] = np.full((n, n), np.nan)
+            assert sched[l]["xU"] == 0, "a recomputing level has no U halo to exchange"
         Fc = orc.doRestriction(n, -orc.getResidual(n, L, Ul, F[l]), M)
         table_lo, _w = mg.restriction_table(n, M)
         if l + 1 < first_collapsed:
@@ -152,6 +155,9 @@ def main():
         # this rank computed redundantly itself one node earlier (ext of the coarser level), and this level's own U
         # and F halos are there since the descent (recomputed, or exchanged right after the level's -1 launch)
         Uc = U[l + 1]
+        if sched[l]["pre"]:
+            # the recomputing `1` launch: the pre-smoothed field once more, from zero, out of the F rows of the window
+            U[l], _ = orc.doSmoothing(n, L, np.zeros((n, n)), F[l], sched[l]["pre"])
         Uf = orc.doGridAddition(n, U[l], orc.doProlongation(M, Uc, n, fill=np.nan))
         Ul, _ = orc.doSmoothing(n, L, Uf, F[l], step)
         assert not np.isnan(Ul[ext[0]:ext[1]]).any(), f"rank {rank}: NaN in the rows the 1 launch of level {n} updates"

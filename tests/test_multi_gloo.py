@@ -47,13 +47,31 @@ def test_partition_properties():
     import multigrid_poisson_solver_amd as mg
     G = mg.slab_ghost_rows()
     assert G >= 6
-    # the bench configurations: the halos of the schedule fit, nothing but the last level's U halo travels
-    for N, R in [(16384, 8), (23040, 8), (11520, 2), (16384, 4), (16384, 2)]:
+    # the bench configurations WITH THE PRODUCT'S THRESHOLDS (this process runs with the test suite's lower ones, see
+    # conftest.py: a child process): the halos of the schedule fit, nothing but the last level's U halo travels, and
+    # the levels from 4096 on recompute their pre-smoothed field (such a level has no U halo at all)
+    code = """
+import multigrid_poisson_solver_amd as mg
+for N, R in [(16384, 8), (23040, 8), (11520, 2), (16384, 4), (16384, 2)]:
+    sched = [d for d in mg.slab_schedule(N, 8, R, 1024, 3) if not d["collapsed"]]
+    assert all(d["xF"] == 0 for d in sched) and [d["xU"] > 0 for d in sched] == [False] * (len(sched) - 1) + [True], (N, R)
+    assert [d["pre"] for d in sched] == [3 if d["N"] >= 4096 else 0 for d in sched], (N, R)
+    assert all(d["xU"] == 0 for d in sched if d["pre"])
+    for d in sched:
+        rows = min(hi - lo for lo, hi in d["own"])
+        assert d["halo"] <= rows // 8, (N, R, d["N"], d["halo"], rows)
+        for r in range(R):
+            assert d["dext"][r][0] <= d["own"][r][0] and d["dext"][r][1] >= d["own"][r][1]
+print("SCHEDULE_OK")
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("MG_RECOMPUTE_MIN_N", "MG_NT_MIN_N")}
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "SCHEDULE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    # with the thresholds of the tests: every recomputing level is free of U halos, slabs contain their dext rows
+    for N, R in [(16384, 8), (23040, 8), (11520, 2)]:
         sched = [d for d in mg.slab_schedule(N, 8, R, 1024, 3) if not d["collapsed"]]
-        assert all(d["xF"] == 0 for d in sched) and [d["xU"] > 0 for d in sched] == [False] * (len(sched) - 1) + [True]
+        assert all(d["xU"] == 0 for d in sched if d["pre"])
         for d in sched:
-            rows = min(hi - lo for lo, hi in d["own"])
-            assert d["halo"] <= rows // 8, (N, R, d["N"], d["halo"], rows)
             for r in range(R):
                 assert d["dext"][r][0] <= d["own"][r][0] and d["dext"][r][1] >= d["own"][r][1]
     for N, R, collapse in [(8192, 8, 1024), (23040, 8, 1024), (11520, 2, 1024), (23168, 8, 1024), (1024, 3, 128), (16384, 4, 512)]:
