@@ -97,7 +97,13 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
         # compulsory bytes of a slab launch: the node kernel's bytes on this rank's share of the rows
         share = 1.0 / world
         n = float(N) * N * share
-        cb = (16.0 * n + 2.0 * n) if "restrict" in e["name"] else ((24.0 * n + 2.0 * n) if "prolong" in e["name"] else 24.0 * n)
+        # (noU / pre3: the node pair that neither stores nor re-reads the pre-smoothed field, levels >= 4096)
+        if "restrict" in e["name"]:
+            cb = (8.0 if "noU" in e["name"] else 16.0) * n + 2.0 * n
+        elif "prolong" in e["name"]:
+            cb = (16.0 if "pre" in e["name"] else 24.0) * n + 2.0 * n
+        else:
+            cb = 24.0 * n
         kernels.append({"kernel": e["name"], "N": e["N"], "launches": e["launches"], "avg_ms": round(avg, 4),
                         "compulsory_GBs": round(cb * elem / (avg * 1e-3) / 1e9, 1) if avg > 0 else None,
                         "algorithmic_equiv_GBs": round(e["algo_bytes"] / (avg * 1e-3) / 1e9, 1) if avg > 0 else None})
@@ -114,8 +120,8 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
         "N": N, "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
         "ms_per_step": round(ms_per_step, 4),
         "workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
-                    f"{len(sizes)} levels, {world} row slabs, communication-avoiding schedule (F halos recomputed, ONE RCCL group per "
-                    f"cycle on a second stream: collapse all-gather + one U halo), levels N<={collapse_N} replicated on every rank",
+                    f"{len(sizes)} levels, {world} row slabs, communication-avoiding schedule (F halos recomputed, the pre-smoothed U of the levels >= 4096 recomputed instead of "
+                    f"stored/re-read/exchanged, ONE RCCL group per cycle on a second stream: collapse all-gather + one U halo), levels N<={collapse_N} replicated on every rank",
         "levels": len(sizes), "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1), "mg_error": r["mg_error"],
         "roofline": roof, "kernels": kernels[:6],
         # where rank 0's time went (live hipEvent pairs): its kernel launches, its ghost exchanges (which
