@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -262,6 +263,39 @@ def test_headline_size_cycles_vs_oracle(mg, oracle, tmp_path, kind):
     assert len(got["records"]) == len(want["records"])
     for g, w in zip(got["records"], want["records"]):
         assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    plan.close()
+
+
+def test_product_thresholds_against_the_oracle_and_against_the_test_thresholds(mg, oracle, tmp_path):
+    """The suite runs the large-grid code paths (recomputing node pair, non-temporal stores) from small sizes on
+    (conftest.py).  Here the library runs with ITS OWN thresholds in a child process -- the configuration bench.py
+    measures: recomputing pair from N = 4096, store/re-read below -- at N = 8192 against the oracle (checksum of the
+    final U, analytic error, every smoothing error) and at N = 16384 against this process's run of the same file."""
+    import _synth
+    env = {k: v for k, v in os.environ.items() if k not in ("MG_RECOMPUTE_MIN_N", "MG_NT_MIN_N", "MG_F32_COLS4_MIN_N")}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_defaults_worker.py"), "8192", "16384"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
+    assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-3000:]
+    import json
+    child = json.loads(line[0][len("DEFAULTS_WORKER "):])
+    path = str(tmp_path / "V8192.txt")
+    mg.write_vcycle_file(path, 8192, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path, want_report=False)
+    assert want["status"] == 0 and child["8192"]["status"] == 0
+    assert tuple(child["8192"]["sum"]) == _synth.checksum(want["U"]), "product thresholds: final U at N = 8192 differs from the oracle's"
+    assert child["8192"]["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+    for g, w in zip(child["8192"]["errors"], want["records"]):
+        assert g == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    N = 16384
+    path = str(tmp_path / "V16384.txt")
+    mg.write_vcycle_file(path, N, 8, 3, 1e-7)
+    plan = mg.CyclePlan(path, fused=True, report=False)
+    got = plan.execute()
+    s = (C.c_uint64 * 2)()
+    mg.lib().mg_checksum(got["U_ptr"], N * N, s)
+    assert got["status"] == 0 and child["16384"]["status"] == 0
+    assert [int(s[0]), int(s[1])] == child["16384"]["sum"], "N = 16384: the two threshold configurations disagree"
     plan.close()
 
 
