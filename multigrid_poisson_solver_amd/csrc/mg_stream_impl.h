@@ -32,6 +32,10 @@
 //     residual D itself then never touches HBM.
 // With both, a V-cycle level costs  F + U + F_coarse (18 B/point) on the way down and
 // U + coarse + F + U (26 B/point) on the way up.
+//   * PRE > 0 (the fused `1` node of the big levels): the U the `-1` node smoothed from zero is not read -- that node
+//     did not even store it (no_out) -- but recomputed in the same pass: PRE sweeps from the zero field on the same F
+//     (levels 1..PRE), the prolongation added to level PRE, S more sweeps.  The level pair then costs
+//     F + F_coarse (10 B/point) down and coarse + F + U (18 B/point) up, for PRE more sweeps of arithmetic.
 //
 // Every point is updated with exactly the reference's expression and association order
 // (-ffp-contract=off), so the result is bit-identical to S separate sweeps; a halo point
