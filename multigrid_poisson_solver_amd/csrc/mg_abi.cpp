@@ -740,12 +740,12 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     if (sf.Fc) bytes += 4.0 * n + 1.0 * n;
     if (sf.coarse) bytes += 8.0 * n + 1.0 * n;
     char name[48];
-    snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s>", step, U_in ? "" : ",zero", sf.coarse ? ",prolong" : "",
-             sf.Fc ? ",res,restrict" : "");
+    snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
+             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", sf.pre ? ",pre3" : "");
     ProfScope ps(name, N, bytes);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, (const float *)sf.coarse,
                          sf.Nc, pt, (float *)sf.Fc, sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr,
-                         sf.Fc ? &sf.fc_w : nullptr);
+                         sf.Fc ? &sf.fc_w : nullptr, nullptr, nullptr, -1, sf.pre, sf.no_out);
 }
 }  // namespace mg
 
@@ -917,7 +917,7 @@ void mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, fl
 namespace mg {
 namespace {
 void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const float *U_in, float *U_out, double *U_out_wide,
-                             const float *F, int step, double *error_dev)
+                             const float *F, int step, double *error_dev, int pre = 0)
 {
     if (!require_ready("mg_prolong_smooth_f32") || !grid_args_ok("mg_prolong_smooth_f32", N) ||
         !grid_args_ok("mg_prolong_smooth_f32", Nc))
@@ -932,6 +932,10 @@ void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const fl
     }
     const double dx2 = spacing_sq(N, L);
     const size_t n = (size_t)N * N;
+    if (pre && (!k::stream_fusable(N) || !pt.fusable)) {
+        fail(MG_ERR_UNSUPPORTED, "prolong_smooth_f32_recompute: needs the fused form (Nc=%d N=%d)", Nc, N);
+        return;
+    }
     if (!k::stream_fusable(N) || !pt.fusable) {
         // odd or non-nested sizes: prolongation + addition as a gather, then the sweeps
         if (U_out_wide) {
@@ -952,12 +956,38 @@ void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const fl
         scratch_pool().put(tmp);
         return;
     }
-    ProfScope ps(U_out_wide ? "jacobi_stream_f32<prolong,widen>" : "jacobi_stream_f32<prolong>", N,
-                 (double)n * (12.0 * step + 8.0 + (U_out_wide ? 12.0 : 0.0)) + 4.0 * Nc * Nc);
-    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,
-                         nullptr, nullptr, nullptr, nullptr, U_out_wide);
+    ProfScope ps(pre ? (U_out_wide ? "jacobi_stream_f32<prolong,widen,pre3>" : "jacobi_stream_f32<prolong,pre3>")
+                     : (U_out_wide ? "jacobi_stream_f32<prolong,widen>" : "jacobi_stream_f32<prolong>"),
+                 N, (double)n * (12.0 * (step + pre) + 8.0 + (U_out_wide ? 12.0 : 0.0)) + 4.0 * Nc * Nc);
+    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), pre ? nullptr : U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,
+                         nullptr, nullptr, nullptr, nullptr, U_out_wide, nullptr, -1, pre, false);
 }
 }  // namespace
+
+void smooth_restrict_f32_no_out(int N, double L, float *U_unused, float *F, int step, double *error_dev, int M, float *F_c)
+{
+    Context &c = ctx();
+    const RestrictTable &rt = restrict_table(N, M);
+    if (!rt.lo || !rt.fusable || !k::stream_fusable(N) || step < 1 || step > k::stream_max_steps()) {
+        fail(MG_ERR_UNSUPPORTED, "smooth_restrict_f32_no_out: N=%d M=%d step=%d is not a fused `-1` node", N, M, step);
+        return;
+    }
+    const double dx2 = spacing_sq(N, L);
+    const size_t n = (size_t)N * N;
+    ProfScope ps("jacobi_stream_f32<restrict,noU>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
+    k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_unused, step, error_dev, nullptr, 0, nullptr, F_c, M, &rt,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, -1, 0, true);
+}
+
+void prolong_smooth_f32_recompute(int Nc, const float *U_c, int N, double L, float *U_out, double *U_out_wide, const float *F, int pre,
+                                  int step, double *error_dev)
+{
+    if (!recompute_available(Nc, N, pre, step)) {
+        fail(MG_ERR_UNSUPPORTED, "prolong_smooth_f32_recompute: Nc=%d N=%d pre=%d step=%d", Nc, N, pre, step);
+        return;
+    }
+    prolong_smooth_f32_impl(Nc, U_c, N, L, nullptr, U_out, U_out_wide, F, step, error_dev, pre);
+}
 
 void prolong_smooth_f32_wide(int Nc, const float *U_c, int N, double L, const float *U_in, double *U_out_wide, const float *F,
                              int step, double *error_dev)

@@ -350,6 +350,7 @@ int trigger_smoothing(Exec &x, LevelNode *lv)
 void ensure_U(mg_cycle_plan *p, LevelNode *lv)
 {
     if (!lv || lv->pending_pre <= 0) return;
+    if (p->flags & MG_CYCLE_MIXED) return;  // fp32 fields: every consumer is a fused `1` node (anything else is status 15)
     mg_smooth_pp(lv->N, p->L, nullptr, lv->U, lv->F, lv->pending_pre, nullptr, nullptr, -1);
     lv->pending_pre = 0;
 }
@@ -539,8 +540,16 @@ void run_nodes(Exec &x)
                 report_smoothing(p, rec);
                 cycle.Push_back(next_N);  // :283
                 if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }
-                mg_smooth_restrict_f32(lv->N, p->L, nullptr, (float *)lv->U, (float *)lv->F, step, error_slot(p, rec), next_N,
-                                       (float *)cycle.last()->F);
+                lv->pending_pre = 0;
+                if (p->con_step > 0 && recompute_available(next_N, lv->N, step, p->con_step)) {
+                    // (as in the fp64 driver below: the level's `1` node redoes these sweeps, U is neither written nor read)
+                    smooth_restrict_f32_no_out(lv->N, p->L, (float *)lv->U, (float *)lv->F, step, error_slot(p, rec), next_N,
+                                               (float *)cycle.last()->F);
+                    lv->pending_pre = step;
+                } else {
+                    mg_smooth_restrict_f32(lv->N, p->L, nullptr, (float *)lv->U, (float *)lv->F, step, error_slot(p, rec), next_N,
+                                           (float *)cycle.last()->F);
+                }
                 if (x.c.last_error) { x.status = 15; break; }
                 report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
                 if (!try_tail(x) && next_N <= k::TAIL_MAX_N) { x.status = 15; break; }
@@ -616,10 +625,20 @@ void run_nodes(Exec &x)
                 const bool last_node = fine->N == p->N_max && p->refinements == 1 && k::stream_fusable(fine->N) &&
                                        prolong_table(coarse->N, fine->N).fusable &&
                                        (x.tok >= p->tokens.size() || (int)p->tokens[x.tok] == 2);
+                const int pre = fine->pending_pre;  // > 0: the `-1` node of this level left U to be recomputed here
+                if (pre > 0 && !recompute_available(coarse->N, fine->N, pre, step)) { x.status = 15; break; }  // (cannot happen: same test as there)
+                fine->pending_pre = 0;
                 if (last_node) {
-                    prolong_smooth_f32_wide(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, p->U64,
-                                            (const float *)fine->F, step, error_slot(p, rec));
+                    if (pre > 0)
+                        prolong_smooth_f32_recompute(coarse->N, (const float *)coarse->U, fine->N, p->L, nullptr, p->U64, (const float *)fine->F,
+                                                     pre, step, error_slot(p, rec));
+                    else
+                        prolong_smooth_f32_wide(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, p->U64,
+                                                (const float *)fine->F, step, error_slot(p, rec));
                     x.widened = true;
+                } else if (pre > 0) {
+                    prolong_smooth_f32_recompute(coarse->N, (const float *)coarse->U, fine->N, p->L, (float *)fine->U, nullptr,
+                                                 (const float *)fine->F, pre, step, error_slot(p, rec));
                 } else {
                     mg_prolong_smooth_f32(coarse->N, (const float *)coarse->U, fine->N, p->L, (const float *)fine->U, (float *)fine->D,
                                           (float *)fine->F, step, error_slot(p, rec));

@@ -243,7 +243,8 @@ void checksum(hipStream_t s, const double *src, size_t n, uint64_t *out_dev /*[2
 void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                        double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
                        const RestrictTable *rt, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
-                       const RowWindow *fc_w = nullptr, double *out_wide = nullptr, float *D_out = nullptr, int d_sign = -1);
+                       const RowWindow *fc_w = nullptr, double *out_wide = nullptr, float *D_out = nullptr, int d_sign = -1,
+                       int pre = 0, bool no_out = false);  // pre / no_out: as in jacobi_stream
 // coarse tail of a cycle in one launch (mg_tail.hip): the node slice that stays on levels N <= 64
 constexpr int TAIL_MAX_LEVELS = 6;
 constexpr int TAIL_MAX_NODES = 48;
@@ -294,6 +295,10 @@ bool recompute_available(int Nc, int N, int pre, int step);
 int  recompute_min_n();   // MG_RECOMPUTE_MIN_N (default 4096)
 void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c);
 void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double *U_out, double *F, int pre, int step, double *error_dev);
+// the same pair on fp32 fields (mixed-precision mode); U_out_wide != nullptr: the result is stored in fp64 there
+void smooth_restrict_f32_no_out(int N, double L, float *U_unused, float *F, int step, double *error_dev, int M, float *F_c);
+void prolong_smooth_f32_recompute(int Nc, const float *U_c, int N, double L, float *U_out, double *U_out_wide, const float *F, int pre,
+                                  int step, double *error_dev);
 // mg_prolong_smooth_f32 whose result goes to an fp64 array (exact widening in the store) instead of U_out
 void prolong_smooth_f32_wide(int Nc, const float *U_c, int N, double L, const float *U_in, double *U_out_wide, const float *F,
                              int step, double *error_dev);

@@ -537,8 +537,8 @@ void run(mg_slab_plan *p)
                     sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse, r);
                     sf.pre = p->lp[hier].pre;
                     if (p->mixed)
-                        slab_smooth_f32(fine.N, p->L, (const float *)fine.loc[i].U, (float *)fine.loc[i].D, (const float *)fine.loc[i].F,
-                                        step, raw_slot(p, (size_t)rec, i), sf);
+                        slab_smooth_f32(fine.N, p->L, sf.pre ? nullptr : (const float *)fine.loc[i].U, (float *)fine.loc[i].D,
+                                        (const float *)fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
                     else
                         slab_smooth(fine.N, p->L, sf.pre ? nullptr : fine.loc[i].U, fine.loc[i].D, fine.loc[i].F, step,
                                     raw_slot(p, (size_t)rec, i), sf);
@@ -572,7 +572,7 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 // ca_mode: 0 = exchange every halo (one group per level, the round-1 schedule), 1 = recompute F halos (default),
 // 2 = recompute the U halos as well (no ghost exchange at all, only the collapse all-gather).
 // recompute_min: levels at least this large run the node pair that neither stores nor re-reads the pre-smoothed U
-// (0 = none: mixed-precision plans, MG_SLAB_RECOMPUTE=0): their `1` launch reads F on grow(ext, 2*steps + 2) and no
+// (0 = none: MG_SLAB_RECOMPUTE=0): their `1` launch reads F on grow(ext, 2*steps + 2) and no
 // U at all, so such a level has no U halo to recompute or to exchange
 static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Partition> &parts, const std::vector<bool> &collapsed,
                           int nranks, int steps, int ca_mode, int max_pct, int recompute_min, std::vector<LevelPlan> *out)
@@ -698,7 +698,8 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
 static int slab_recompute_min(bool mixed)
 {
     static const bool on = [] { const char *e = getenv("MG_SLAB_RECOMPUTE"); return !e || atoi(e) != 0; }();
-    return (mixed || !on || ctx().smoother == SMOOTHER_SIMPLE) ? 0 : recompute_min_n();
+    (void)mixed;  // fp32 slabs run the same pair
+    return (!on || ctx().smoother == SMOOTHER_SIMPLE) ? 0 : recompute_min_n();
 }
 
 static int slab_ca_mode()

@@ -13,7 +13,7 @@ namespace k {
 void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                        double *err_out, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
                        const RestrictTable *rt, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
-                       double *out_wide, float *D_out, int d_sign)
+                       double *out_wide, float *D_out, int d_sign, int pre, bool no_out)
 {
     f32::StreamTables tb;
     if (coarse) {
@@ -32,7 +32,7 @@ void jacobi_stream_f32(hipStream_t s, int N, float dx2, float inv, const float *
         tb.r_w = rt->w_f;
         tb.r_wf = rt->inv_w_f;
     }
-    f32::run(s, N, dx2, inv, in, F, out, steps, err_out, D_out, d_sign, coarse, Nc, Fc, M, tb, fine_w, coarse_w, fc_w, out_wide);
+    f32::run(s, N, dx2, inv, in, F, out, steps, err_out, D_out, d_sign, coarse, Nc, Fc, M, tb, fine_w, coarse_w, fc_w, out_wide, pre, no_out);
 }
 
 }  // namespace k

@@ -958,8 +958,9 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
     const bool nt = p.N >= p.nt_min_n;
     if constexpr (sizeof(real_t) == 4) {
         // fp32 fields, 16 B per lane: the same kernel with 4 columns per lane (8 B per lane leaves it bound by its
-        // instruction stream at half the bytes per instruction of the fp64 build)
-        if (p.cols4) {
+        // instruction stream at half the bytes per instruction of the fp64 build).  Not the recomputing `1` node: its
+        // 6-level pipeline needs 267 VGPRs with 4 columns (one wave per SIMD: 270 us at N = 8192) and 144 with 2
+        if (p.cols4 && !(prolong_in && p.pre)) {
             if (restrict_out) {
                 if (zero) launch_k<S, 4, IN_ZERO, true, PF>(s, p, err_out);
                 else launch_k<S, 4, IN_LOAD, true, PF>(s, p, err_out);
@@ -980,7 +981,7 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
-        if constexpr (S == 3 && PF == 2 && sizeof(real_t) == 8) {
+        if constexpr (S == 3 && PF == 2) {
             if (p.pre == 3) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
                 if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true, 3>(s, p, err_out);
                 else launch_k<S, 2, IN_PROLONG, false, PF, false, 3>(s, p, err_out);
@@ -1016,8 +1017,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
                 const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
                 double *out_wide = nullptr, int pre = 0, bool no_out = false)
 {
-    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc && !out_wide && sizeof(real_t) == 8)) {
-        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused fp64 `1` node (pre=%d steps=%d)", pre, steps);
+    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc)) {
+        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
         return;
     }
     if (steps < 1 || steps > MAX_S) {
