@@ -988,6 +988,10 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
                 return;
             }
         }
+        if (p.pre != 0) {  // (no instantiation for this S / PF: never read the absent input through the plain node)
+            fail(MG_ERR_UNSUPPORTED, "jacobi_stream: no recomputing `1` node for %d sweeps, prefetch depth %d", S, PF);
+            return;
+        }
         if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true>(s, p, err_out);
         else launch_k<S, 2, IN_PROLONG, false, PF>(s, p, err_out);
     } else {
@@ -1001,7 +1005,8 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 {
     // rows in flight per lane: PF = 2 (a FIFO of 4 slots).  A deeper FIFO (PF = 3 at the same occupancy, PF = 4, 8) costs registers
     // and a longer prologue and measured slower at every size from 128 to 8192 once all loads were
-    // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).
+    // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).  Round 2, for the `-1` node
+    // that no longer stores U (it loads F alone): PF = 3 gives 147 against 151 us at N = 8192, nothing below -- not taken.
 #ifndef MG_PF
 #define MG_PF 2
 #endif
