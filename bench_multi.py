@@ -73,8 +73,10 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
     plan.want_error(True)
     r = plan.execute()  # untimed: the result's error against the analytic solution
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms_per_step = float(t.item()) * 1e3 / args.steps
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)   # each rank's own clock around the same K windows (the barriers bracket all of them)
+    per_rank_ms = [float(e.item()) * 1e3 / args.steps for e in every]
+    ms_per_step = max(per_rank_ms)   # the contract: MAX over ranks
     plan.close()
     mg.lib().mg_pool_trim()
     if rank != 0:
@@ -119,6 +121,8 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
     return {
         "N": N, "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
         "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_ranks": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
+                              "all": [round(v, 4) for v in per_rank_ms]},
         "workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
                     f"{len(sizes)} levels, {world} row slabs, communication-avoiding schedule (F halos recomputed, the pre-smoothed U of the levels >= 4096 recomputed instead of "
                     f"stored/re-read/exchanged, ONE RCCL group per cycle on a second stream: collapse all-gather + one U halo), levels N<={collapse_N} replicated on every rank",
@@ -160,6 +164,7 @@ def run(args, rank, world, local_rank):
 
     mg.init(local_rank)
     mg.set_smoother("stream")
+    wire = {"transport": "none (one rank)", "nranks": 1, "lib": "", "selftest": None}
     if world > 1:
         if rehearsal:
             host_transport(mg, rank, world)
@@ -171,6 +176,17 @@ def run(args, rank, world, local_rank):
             # stream, all-gather over all ranks) must deliver their bytes
             if mg.lib().mg_comm_selftest(1 << 16) != 0:
                 raise SystemExit(f"rank {rank}: RCCL self-test failed: {mg.lib().mg_last_error_string()}")
+        # what the record needs to certify itself: the communicator's own rank count (not the environment's), the shared
+        # object the nccl* entry points were resolved from, the self-test's verdict -- from EVERY rank
+        mine = {"rank": mg.lib().mg_comm_rank(), "nranks": mg.lib().mg_comm_size(), "lib": (mg.lib().mg_comm_library() or b"").decode(),
+                "device": local_rank}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        wire = {"transport": "host-staged over gloo (rehearsal)" if rehearsal else "rccl",
+                "nranks": mine["nranks"], "lib": mine["lib"], "selftest": None if rehearsal else 0,
+                "ranks_agree": all(x["nranks"] == world and x["lib"] == mine["lib"] for x in seen) and
+                               sorted(x["rank"] for x in seen) == list(range(world)),
+                "devices": [x["device"] for x in seen]}
 
     tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
     N_weak = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n
@@ -193,13 +209,13 @@ def run(args, rank, world, local_rank):
             "config": {"workload": head["workload"], "N": head["N"], "levels": head["levels"], "parallelism": f"slab{world}"},
             "fine_dof_per_s": head["fine_dof_per_s"], "mg_error": head["mg_error"], "roofline": head["roofline"],
             "kernels": head["kernels"], "rank0_ms_per_step": head["rank0_ms_per_step"], "ghost_exchanges": head["ghost_exchanges"],
-            "cycle_roofline": head["cycle_roofline"],
+            "cycle_roofline": head["cycle_roofline"], "ms_per_step_ranks": head["ms_per_step_ranks"], "rccl": wire,
             **({"transport": "host-staged over gloo, all ranks on ONE GPU: a plumbing rehearsal, not a measurement"}
                if rehearsal and world > 1 else {}),
         }
         if other:
             out[name] = {k: other[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
-                                               "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline")}
+                                               "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline", "ms_per_step_ranks")}
             out[name]["scaling"] = "strong" if name == "strong_scaling" else "weak"
         print(json.dumps(out), flush=True)
     if world > 1:

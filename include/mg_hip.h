@@ -75,7 +75,10 @@ void mg_getSource(int N, double L, double *F, double min_x, double min_y);
  * "auto" (default): on the device (k_source: no host pass, no PCIe) when that reproduces THIS host's libm bit for
  *   bit -- the reference calls libm's exp() (:488), and the device evaluates glibc's algorithm for it (table +
  *   polynomial, FMA form); the engine compares the two on ~130k points once per process (mg_source_is_bit_identical)
- *   and falls back to "host" when they differ (another libm, a CPU without FMA);
+ *   and falls back to "host" when they differ (another libm, a CPU without FMA), and per call for grids whose
+ *   arguments x - y leave the verified main path of the algorithm (|min_x - min_y| + |L| >= 511: glibc's overflow
+ *   and subnormal special cases are not reproduced on the device).  mg_getAnalytic / mg_analyticError always use the
+ *   device form: outside that range their exp() is the device's own (<= 1 ulp from libm's);
  * "host": libm on the host cores, chunked through 2 x 128 MiB of pinned staging;
  * "device": the device form unconditionally.  Also env MG_SOURCE. */
 int  mg_set_source(const char *mode);
@@ -167,7 +170,7 @@ void mg_checksum(const double *src, size_t n_doubles, uint64_t out[2]);
 /* the engine's stream around every operator launch on grids with N >= min_N     */
 /* ------------------------------------------------------------------------- */
 typedef struct mg_profile_entry {
-    char   name[40];        /* kernel family, e.g. "jacobi_stream<3>" */
+    char   name[64];        /* kernel family, e.g. "jacobi_stream<3>" */
     int    N;               /* grid size */
     int    launches;
     double total_ms;        /* sum of the launches' durations */
@@ -257,6 +260,10 @@ int  mg_comm_selftest(size_t n_doubles);
 void mg_comm_finalize(void);
 int  mg_comm_rank(void);
 int  mg_comm_size(void);
+/* the shared object the RCCL entry points in use were resolved from (absolute path as the loader mapped it), "host
+ * transport ..." after mg_comm_init_host, "" before any communicator exists: lets a benchmark record prove which wire
+ * and how many ranks (mg_comm_size) it ran on */
+const char *mg_comm_library(void);
 
 /* host-only: row ranges per level and rank of the hierarchy N_max, N_max/2, ... >= N_min.
  * out[(level*nranks + rank)*2 + {0,1}] = [lo, hi); collapsed_out[level] = 1 where the level
@@ -283,6 +290,11 @@ int  mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int step
  * at least MG_RECOMPUTE_MIN_N = 4096 points per side; MG_SLAB_RECOMPUTE=0 switches it off): such a level has no U
  * halo.  Returns the number of levels. */
 int  mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out);
+/* host-only: 1 when this build holds the recomputing fused `1` node for `pre` pre-smoothing + `post` post-smoothing
+ * sweeps (1+1, 2+2, 3+3 in the default build; none in a build with another prefetch depth): the node pair that
+ * neither stores nor re-reads a level's pre-smoothed U (src/MG_solver_CPU.cpp:259 ... :416 of one level).  Other
+ * sweep counts -- and cycle files with per-node step counts, con_step = 0 -- run the store/re-read form. */
+int  mg_recompute_pair_available(int pre, int post);
 
 typedef struct mg_slab_plan mg_slab_plan;
 /* rank >= 0: this process is that rank (needs mg_comm_init when nranks > 1).  rank == -1:

@@ -30,7 +30,7 @@ class NodeRecord(C.Structure):
 
 
 class ProfileEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 40), ("N", C.c_int), ("launches", C.c_int), ("total_ms", C.c_double),
+    _fields_ = [("name", C.c_char * 64), ("N", C.c_int), ("launches", C.c_int), ("total_ms", C.c_double),
                 ("algo_bytes", C.c_double)]
 
 
@@ -82,10 +82,12 @@ ABI = {
     "mg_comm_init_host": (_i, [_i, _i, _vp]),
     "mg_comm_init": (_i, [_i, _i, _vp]), "mg_comm_finalize": (None, []), "mg_comm_selftest": (_i, [_sz]), "mg_comm_rank": (_i, []),
     "mg_comm_size": (_i, []),
+    "mg_comm_library": (C.c_char_p, []),
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
     "mg_slab_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mg_slab_recompute_levels": (_i, [_i, _i, _i, _vp]),
+    "mg_recompute_pair_available": (_i, [_i, _i]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),

@@ -67,7 +67,7 @@ def build(force=False, verbose=False):
               f"-ffile-prefix-map={ROOT}=."]
     common += os.environ.get("MG_EXTRA_CXXFLAGS", "").split()
     if force or _stale(LIB, deps):
-        objs = []
+        objs, jobs = [], []
         for s in srcs:
             o = os.path.join(PKG, "lib", os.path.basename(s) + ".o")
             if force or _stale(o, deps if s.endswith(".hip") else [s] + deps[len(srcs):]):
@@ -78,10 +78,16 @@ def build(force=False, verbose=False):
                     # the coarse tail is one workgroup whose exact solver is ONE wave running a 2 KB loop: with the loop
                     # heads on instruction-cache lines the solve measured 10 % faster (the streaming kernels: no change)
                     cmd.insert(-4, "-falign-loops=64")
-                if verbose:
-                    print(" ".join(cmd))
-                subprocess.run(cmd, check=True)
+                jobs.append(cmd)
             objs.append(o)
+        # the compilation units are independent: one hipcc per core (the two streaming-kernel units are most of the time)
+        from concurrent.futures import ThreadPoolExecutor
+        def _run(cmd):
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs) or 1, os.cpu_count() or 1, 8))) as ex:
+            list(ex.map(_run, jobs))
         # RCCL is resolved with dlopen on the first communicator call (mg_comm.cpp): no -lrccl here
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         if verbose:

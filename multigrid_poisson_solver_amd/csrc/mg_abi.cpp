@@ -290,9 +290,10 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
             // zero-fill, + 24 for a folded residual, + 8n + 8m for a folded restriction,
             // + 8m + 16n for a folded prolongation+addition; the fused error costs nothing
             const bool pro = (i == 0 && fu.coarse), res = last && (D_out || fu.Fc), rst = last && fu.Fc;
-            char name[40];
+            char name[48], pre_tag[8] = "";
+            if (fu.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", fu.pre);
             snprintf(name, sizeof name, "jacobi_stream<%d%s%s%s%s%s%s>", take, (src || fu.pre) ? "" : ",zero", pro ? ",prolong" : "",
-                     res ? ",res" : "", rst ? ",restrict" : "", fu.no_out ? ",noU" : "", fu.pre ? ",pre3" : "");
+                     res ? ",res" : "", rst ? ",restrict" : "", fu.no_out ? ",noU" : "", pre_tag);
             double bytes = (double)n * (24.0 * (take + fu.pre) + ((src || fu.pre) ? 0.0 : 8.0) + (res ? 24.0 : 0.0));
             if (rst) bytes += 8.0 * n + 8.0 * fu.M * fu.M;
             if (pro) bytes += 16.0 * n + 8.0 * fu.Nc * fu.Nc;
@@ -332,9 +333,14 @@ int recompute_min_n()
 bool recompute_available(int Nc, int N, int pre, int step)
 {
     const int min_n = recompute_min_n();
-    if (pre != 3 || step != 3 || N < min_n || ctx().smoother == SMOOTHER_SIMPLE || !k::stream_fusable(N)) return false;
+    if (!k::stream_recompute_supported(pre, step) || N < min_n || ctx().smoother == SMOOTHER_SIMPLE || !k::stream_fusable(N)) return false;
+    // BOTH nodes of the pair must be fused launches: the `1` node's prolongation Nc -> N (owners advance by at most one)
+    // and the `-1` node's restriction N -> Nc (samples at least two fine columns apart: non-nested pairs such as
+    // 4096 -> 3000 or con_N = 2's N -> N - 1 are not, and run store/re-read operator by operator)
     const ProlongTable &pt = prolong_table(Nc, N);
-    return pt.owner_row && pt.fusable;
+    if (!pt.owner_row || !pt.fusable) return false;
+    const RestrictTable &rt = restrict_table(N, Nc);
+    return rt.lo && rt.fusable;
 }
 
 void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c)
@@ -626,7 +632,11 @@ void fill_source_rows(int N, double L, double min_x, double min_y, int row_lo, i
 {
     if (row_hi <= row_lo) return;
     Context &c = ctx();
-    if (source_on_device()) {  // no host pass, no PCIe: k_source evaluates libm's exp() algorithm on the device
+    // exp_libm reproduces glibc's MAIN path (2^-54 <= |x| < 512, and the |x| < 2^-54 shortcut); past that glibc has special
+    // cases (overflow, subnormal results) the device evaluates with its own exp().  In auto mode the device form is
+    // therefore taken only for grids whose every argument x - y stays on the verified path: |min_x - min_y| + |L| < 512.
+    const bool in_verified_range = std::fabs(min_x - min_y) + std::fabs(L) < 511.0;
+    if (source_on_device() && (in_verified_range || c.source_mode == 2)) {  // no host pass, no PCIe: k_source evaluates libm's exp() algorithm on the device
         k::source_device(c.stream, N, L, dev_dst, min_x, min_y, row_lo, row_hi);
         return;
     }
@@ -701,9 +711,10 @@ void slab_smooth(int N, double L, const double *U_in, double *U_out, const doubl
     double bytes = (double)n * (24.0 * step + (U_in ? 0.0 : 8.0) + (sf.Fc ? 24.0 : 0.0));
     if (sf.Fc) bytes += 8.0 * n + 2.0 * n;
     if (sf.coarse) bytes += 16.0 * n + 2.0 * n;
-    char name[40];
+    char name[48], pre_tag[8] = "";
+    if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
     snprintf(name, sizeof name, "slab_stream<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
-             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", sf.pre ? ",pre3" : "");
+             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
     ProfScope ps(name, N, bytes);
     k::jacobi_stream(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, nullptr, -1, sf.coarse, sf.Nc, pt, sf.Fc,
                      sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr, sf.pre, sf.no_out);
@@ -739,9 +750,10 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     double bytes = (double)n * (12.0 * step + (U_in ? 0.0 : 4.0) + (sf.Fc ? 12.0 : 0.0));
     if (sf.Fc) bytes += 4.0 * n + 1.0 * n;
     if (sf.coarse) bytes += 8.0 * n + 1.0 * n;
-    char name[48];
+    char name[56], pre_tag[8] = "";
+    if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
     snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
-             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", sf.pre ? ",pre3" : "");
+             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
     ProfScope ps(name, N, bytes);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, (const float *)sf.coarse,
                          sf.Nc, pt, (float *)sf.Fc, sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr,
@@ -956,8 +968,9 @@ void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const fl
         scratch_pool().put(tmp);
         return;
     }
-    ProfScope ps(pre ? (U_out_wide ? "jacobi_stream_f32<prolong,widen,pre3>" : "jacobi_stream_f32<prolong,pre3>")
-                     : (U_out_wide ? "jacobi_stream_f32<prolong,widen>" : "jacobi_stream_f32<prolong>"),
+    char name[48];
+    snprintf(name, sizeof name, pre ? "jacobi_stream_f32<prolong%s,pre%d>" : "jacobi_stream_f32<prolong%s>", U_out_wide ? ",widen" : "", pre);
+    ProfScope ps(name,
                  N, (double)n * (12.0 * (step + pre) + 8.0 + (U_out_wide ? 12.0 : 0.0)) + 4.0 * Nc * Nc);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), pre ? nullptr : U_in, F, U_out, step, error_dev, U_c, Nc, &pt, nullptr, 0,
                          nullptr, nullptr, nullptr, nullptr, U_out_wide, nullptr, -1, pre, false);
@@ -1160,6 +1173,8 @@ int mg_profile_end(mg_profile_entry *out, int cap)
     c.prof.clear();
     return count;
 }
+
+int mg_recompute_pair_available(int pre, int post) { return k::stream_recompute_supported(pre, post) ? 1 : 0; }
 
 // ------------------------------------------------------------------ tables
 void mg_restriction_table(int N, int M, int *lo, double *w) { build_restriction_table(N, M, lo, w); }

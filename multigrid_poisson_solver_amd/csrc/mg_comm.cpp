@@ -335,4 +335,18 @@ int mg_comm_selftest(size_t n_doubles)
 int mg_comm_rank(void) { return g_rank; }
 int mg_comm_size(void) { return g_nranks; }
 
+// which wire carries the ghost rows: the file the RCCL entry points were resolved from (dladdr of ncclSend: the absolute
+// path the loader mapped, whoever mapped it first), "host transport" for the rehearsal wire, "" before any communicator
+const char *mg_comm_library(void)
+{
+    static std::string text;
+    if (g_host_on) return "host transport (mg_comm_init_host)";
+    if (!g_rccl.handle) return "";
+    Dl_info info;
+    memset(&info, 0, sizeof info);
+    if (g_rccl.Send && dladdr((void *)g_rccl.Send, &info) && info.dli_fname) text = info.dli_fname;
+    else text = g_rccl.where;
+    return text.c_str();
+}
+
 }  // extern "C"

@@ -350,7 +350,7 @@ int trigger_smoothing(Exec &x, LevelNode *lv)
 void ensure_U(mg_cycle_plan *p, LevelNode *lv)
 {
     if (!lv || lv->pending_pre <= 0) return;
-    if (p->flags & MG_CYCLE_MIXED) return;  // fp32 fields: every consumer is a fused `1` node (anything else is status 15)
+    if (p->flags & MG_CYCLE_MIXED) return;  // fp32 fields: every consumer is a fused `1` node (run_nodes turns anything else into status 15)
     mg_smooth_pp(lv->N, p->L, nullptr, lv->U, lv->F, lv->pending_pre, nullptr, nullptr, -1);
     lv->pending_pre = 0;
 }
@@ -704,6 +704,13 @@ void run_nodes(Exec &x)
         }
         // any other token: ignored, as the reference does
     }
+    // Should the level the file ends on still owe its U (pending_pre; today every `-1` node pushes the next level, so
+    // the last level never does): materialise it HERE, as part of the node program, so that a captured graph replays it
+    // too and the work lies inside the timed window of every run.  fp32 fields have no such launch: an explicit status.
+    if (x.status == 0 && cycle.last() && cycle.last()->pending_pre > 0) {
+        if (mixed) x.status = 15;
+        else ensure_U(p, cycle.last());
+    }
     flush_norms();  // the window's smoothing errors: one reduction launch
     x.c.defer_norms = false;
 }
@@ -873,7 +880,6 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         c.active_pool = nullptr;
         p->warm_runs++;
         LevelNode *last = p->levels->last();
-        ensure_U(p, last);
         p->final_U = last->U;
         p->final_N = last->N;
         if (mixed && status == 0 && last->N == p->N_max) {

@@ -204,6 +204,9 @@ void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count);
 int  stream_max_steps();
 bool stream_supported(int N);
 bool stream_fusable(int N);   // the fused prolongation / restriction stages exist for this N
+// the recomputing fused `1` node (pre sweeps from zero redone in flight, then `steps` more) is instantiated for this pair
+// in THIS build (it depends on the prefetch depth the library was compiled with, MG_PF)
+bool stream_recompute_supported(int pre, int steps);
 // coarse != nullptr: level 0 is in + doProlongation(coarse) (tables pt).  Fc != nullptr: the
 // d_sign-ed residual of the result is restricted into Fc (M x M, tables rt).
 // fine_w / coarse_w / fc_w: row windows of the fine arrays, the coarse input and the coarse

@@ -584,7 +584,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
     const int H2 = 2 * steps + 2;  // the same for the 2*steps levels of a recomputing `1` launch
     const size_t R = (size_t)nranks;
     std::vector<LevelPlan> lp(nl);
-    for (size_t l = 0; l < nd; ++l) lp[l].pre = (recompute_min > 0 && steps == 3 && sizes[l] >= recompute_min && sizes[l] % 2 == 0) ? steps : 0;
+    for (size_t l = 0; l < nd; ++l) lp[l].pre = (recompute_min > 0 && k::stream_recompute_supported(steps, steps) && sizes[l] >= recompute_min && sizes[l] % 2 == 0) ? steps : 0;
     // F rows the launches of level `P` read: the `-1` launch around dext, the `1` launch around ext
     auto f_rows = [&](const LevelPlan &P, size_t r, int n) { return unite(grow(P.dext[r], H, n), grow(P.ext[r], P.pre ? H2 : H, n)); };
     // owned rows and the rows of the way up, finest level first
@@ -752,7 +752,7 @@ int mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out)
     int nl = 0;
     const int min_n = slab_recompute_min(false);
     for (int n = N_max; n >= N_min && n > 0; n /= 2, ++nl)
-        if (pre_out) pre_out[nl] = (min_n > 0 && steps == 3 && n >= min_n && n % 2 == 0) ? steps : 0;
+        if (pre_out) pre_out[nl] = (min_n > 0 && k::stream_recompute_supported(steps, steps) && n >= min_n && n % 2 == 0) ? steps : 0;
     return nl;
 }
 

@@ -10,6 +10,7 @@ namespace k {
 int stream_max_steps() { return f64::MAX_S; }
 bool stream_supported(int N) { return N >= 3; }
 bool stream_fusable(int N) { return N >= 4 && N % 2 == 0; }
+bool stream_recompute_supported(int pre, int steps) { return f64::recompute_instantiated(pre, steps); }
 
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out,
                    int steps, double *err_out, double *D_out, int d_sign, const double *coarse, int Nc,

@@ -82,6 +82,18 @@ struct StreamTables {
 constexpr int PF_DEFAULT = 2;    // rows of U and F in flight per lane (FIFO of 2*PF slots)
 constexpr int WAVES_PER_WG = 4;  // 4 adjacent strips of one chunk
 constexpr int MAX_S = 4;
+#ifndef MG_PF
+#define MG_PF 2   // prefetch depth of this build (scripts/build_variant.sh: -DMG_PF=3)
+#endif
+
+// The recomputing fused `1` node (PRE sweeps from zero redone in flight + S post-smoothing sweeps, template parameter
+// PRE of k_jacobi_stream) exists for the pairs a fixed-step cycle file produces, PRE == S, as long as its pipeline of
+// L = PRE + S levels fits the register file at two waves per SIMD: V(1,1), V(2,2), V(3,3).  V(4,4) would be 8 levels
+// (two rows of history each: 64 more VGPRs than the 255 the 6-level kernel already uses) and stays store/re-read.
+// Builds with another prefetch depth have no such instantiation at all.  Everybody who decides to drop a level's U
+// (recompute_available, the slab schedule) asks this function, so a variant build can never drop a field it cannot
+// make again.
+constexpr bool recompute_instantiated(int pre, int steps) { return MG_PF == 2 && pre == steps && pre >= 1 && pre <= 3; }
 
 enum InMode { IN_LOAD = 0, IN_ZERO = 1, IN_PROLONG = 2 };
 
@@ -981,10 +993,10 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
-        if constexpr (S == 3 && PF == 2) {
-            if (p.pre == 3) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
-                if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true, 3>(s, p, err_out);
-                else launch_k<S, 2, IN_PROLONG, false, PF, false, 3>(s, p, err_out);
+        if constexpr (recompute_instantiated(S, S) && PF == 2) {
+            if (p.pre == S) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
+                if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true, S>(s, p, err_out);
+                else launch_k<S, 2, IN_PROLONG, false, PF, false, S>(s, p, err_out);
                 return;
             }
         }
@@ -1007,9 +1019,6 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
     // and a longer prologue and measured slower at every size from 128 to 8192 once all loads were
     // unconditional (fused prolongation: 18.1 vs 21.1 us at N = 1024, 10.9 vs 13.7 us at N = 128).  Round 2, for the `-1` node
     // that no longer stores U (it loads F alone): PF = 3 gives 147 against 151 us at N = 8192, nothing below -- not taken.
-#ifndef MG_PF
-#define MG_PF 2
-#endif
     if constexpr (S <= 3 && MG_PF == 3) launch_variant<S, 3>(s, p, err_out);
     else launch_variant<S, 2>(s, p, err_out);
 }
@@ -1022,8 +1031,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
                 const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
                 double *out_wide = nullptr, int pre = 0, bool no_out = false)
 {
-    if (pre != 0 && !(pre == 3 && steps == 3 && coarse && !Fc)) {
-        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 3 + 3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
+    if (pre != 0 && !(recompute_instantiated(pre, steps) && coarse && !Fc)) {
+        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 1+1, 2+2 and 3+3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
         return;
     }
     if (steps < 1 || steps > MAX_S) {

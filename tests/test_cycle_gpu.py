@@ -83,6 +83,25 @@ def test_generated_vcycle_1024_vs_oracle(mg, oracle, tmp_path, smoother):
         mg.set_smoother("stream")
 
 
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_other_sweep_counts_through_the_cycle_driver(mg, oracle, tmp_path, steps):
+    """V(1,1), V(2,2), V(4,4) and the W-cycle of the same sweep counts: the recomputing node pair (levels from
+    MG_RECOMPUTE_MIN_N on: 256 in this suite) is instantiated for 1+1, 2+2 and 3+3 sweeps, 4+4 falls back to
+    store/re-read (its pipeline of 8 levels does not fit the register file) -- all bit for bit like the oracle, eager and
+    replayed from a graph."""
+    assert mg.lib().mg_recompute_pair_available(steps, steps) == (1 if steps <= 3 else 0)
+    for kind, N in (("V", 1024), ("W", 512)):
+        path = str(tmp_path / f"{kind}{steps}.txt")
+        (mg.write_vcycle_file if kind == "V" else mg.write_wcycle_file)(path, N, 8, steps, 1e-7)
+        want = oracle.run_cycle_file(path)
+        for graph in (False, True):
+            plan = mg.CyclePlan(path, fused=True, graph=graph)
+            for _ in range(3 if graph else 1):
+                got = plan.execute(fetch_U=True)
+            check_against(got, want, zero_sign=True)
+            plan.close()
+
+
 def test_generated_wcycle_full_depth_vs_oracle(mg, oracle, tmp_path):
     """config 3 shape (W-cycle recursion down to N=8) at a size the oracle finishes fast."""
     path = str(tmp_path / "W256.txt")
@@ -173,6 +192,25 @@ def test_manual_grammar_con_step0_con_N0_and_minus_one(mg, oracle, tmp_path):
         want = oracle.run_cycle_file(str(f))
         for fused in (False, True):
             plan = mg.CyclePlan(str(f), fused=fused)
+            check_against(plan.execute(fetch_U=True), want, zero_sign=fused)
+            plan.close()
+
+
+def test_non_nested_pairs_above_the_recompute_threshold(mg, oracle, tmp_path):
+    """Round-2 advisor finding: with con_step = 3 a `-1` node on a level above MG_RECOMPUTE_MIN_N (256 in this suite,
+    conftest.py) whose coarse size is not ~N/2 -- manual sizes (con_N = 0: 300 -> 220) or con_N = 2 (N -> N - 1) -- must
+    not take the recomputing node pair: its restriction is not a fused stage (samples less than two fine columns
+    apart).  The predicate now covers both nodes of the pair; such levels run store/re-read, operator by operator,
+    bit for bit like the oracle."""
+    a = tmp_path / "manual300.txt"
+    a.write_text("1.0 0.0 0.0\n3 0\n300 1\n-1\n220\n-1\n8\n0\n0.0000001 1\n1\n1\n2")
+    b = tmp_path / "minus1_258.txt"
+    b.write_text("1.0 0.0 0.0\n3 2\n258 255\n-1\n-1\n-1\n0\n0.05 1\n1\n1\n1\n2")
+    for f in (a, b):
+        want = oracle.run_cycle_file(str(f))
+        assert want["status"] == 0
+        for fused, graph in ((False, False), (True, False)):
+            plan = mg.CyclePlan(str(f), fused=fused, graph=graph)
             check_against(plan.execute(fetch_U=True), want, zero_sign=fused)
             plan.close()
 

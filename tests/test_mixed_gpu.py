@@ -66,6 +66,28 @@ def test_mixed_cycle_vs_numpy_and_fp64(mg, oracle, tmp_path, kind, N, n_min):
     plan.close()
 
 
+@pytest.mark.parametrize("steps", [1, 2, 4])
+def test_mixed_cycle_other_sweep_counts_vs_numpy(mg, oracle, tmp_path, steps):
+    """The fp32 cycle with 1, 2 and 4 sweeps per node (recomputing pair instantiated for 1+1 and 2+2, store/re-read for
+    4+4) against the numpy restatement, bit for bit."""
+    N, n_min = 1024, 8
+    path = str(tmp_path / "c.txt")
+    mg.write_vcycle_file(path, N, n_min, steps, 1e-7)
+    toks = open(path).read().split()
+    sizes, n = [], N
+    while n >= n_min:
+        sizes.append(n)
+        n //= 2
+    U32, recs = o32.run_cycle_tokens(mg, oracle, oracle.getSource(N), 1.0, steps, sizes, toks[7:])
+    plan = mg.CyclePlan(path, fused=True, mixed=True)
+    got = plan.execute(fetch_U=True)
+    assert got["status"] == 0
+    assert bits32(got["U"].astype(np.float32), U32), f"mixed cycle with {steps} sweeps per node: fp32 result"
+    for g, w in zip(got["records"], recs):
+        assert (g[0], g[1]) == (w[0], w[1]) and g[3] == pytest.approx(w[2], rel=1e-10, abs=1e-300)
+    plan.close()
+
+
 @pytest.mark.parametrize("N", [181, 90])
 def test_fp32_nodes_on_odd_and_non_fusable_sizes(mg, N):
     """Sizes the fused transfer stages do not cover (odd N; the hierarchy 724, 362, 181, 90, 45 of the

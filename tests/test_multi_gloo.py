@@ -22,7 +22,10 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,N,collapse,ca_mode,ca_pct", [(2, 256, 32, 1, 10), (2, 128, 64, 0, 10), (3, 256, 64, 1, 100),
-                                                             (2, 256, 32, 2, 100), (2, 512, 32, 1, 100)])
+                                                             (2, 256, 32, 2, 100), (2, 512, 32, 1, 100),
+                                                             # the target rank count of BASELINE configs[3]/[4]: 8 processes (a GPU box
+                                                             # admits at most 6 processes on its card, so 8 RANKS can only run here)
+                                                             (8, 1024, 64, 1, 10)])
 def test_row_slab_schedule_on_gloo(tmp_path, world, N, collapse, ca_mode, ca_pct):
     """ca_mode 0: every halo exchanged (one group per level); 1: F halos recomputed while the extra rows stay below
     ca_pct per cent of a slab (100: always); 2: U halos recomputed as well (no ghost exchange, only the all-gather)."""
