@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libmgpoisson.so")
 EXE = os.path.join(PKG, "bin", "MG_HIP")
-SOURCES = ["mg_kernels.hip", "mg_stream.hip", "mg_stream_f32.hip", "mg_tail.hip", "mg_tail_f32.hip", "mg_abi.cpp", "mg_tables.cpp", "mg_cycle.cpp", "mg_slab.cpp", "mg_comm.cpp"]
+SOURCES = ["mg_stream_f32.hip", "mg_stream.hip", "mg_tile.hip", "mg_tile_f32.hip", "mg_kernels.hip", "mg_tail.hip", "mg_tail_f32.hip", "mg_abi.cpp", "mg_tables.cpp", "mg_cycle.cpp", "mg_slab.cpp", "mg_comm.cpp"]
 ARCH = "gfx950"
 
 

@@ -280,7 +280,22 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
         double *dst = ((launches - 1 - i) % 2 == 0) ? U_out : partner;
         const bool plain_single = stream && c.smoother != SMOOTHER_STREAM_ONLY && take == 1 && src && !(i == 0 && fu.coarse) && !(last && (D_out || fu.Fc || error_dev)) &&
                                   N >= 2048 && N % 2 == 0;
-        if (plain_single) {
+        // small levels: the whole node as one launch of the register-tile kernel (mg_tile_impl.h) -- the streaming kernel's
+        // march down a column strip is pure latency there.  Same bits.  Not for a stored residual (the unfused driver) and
+        // not for the recomputing pair (large levels only).
+        const bool tile = stream && c.smoother == SMOOTHER_STREAM && launches == 1 && !D_out && fu.pre == 0 && k::tile_wanted(N) &&
+                          take <= k::tile_max_steps();
+        if (tile) {
+            const bool pro = fu.coarse != nullptr, rst = fu.Fc != nullptr;
+            char name[48];
+            snprintf(name, sizeof name, "jacobi_tile<%d%s%s%s%s>", take, src ? "" : ",zero", pro ? ",prolong" : "", rst ? ",res,restrict" : "",
+                     fu.no_out ? ",noU" : "");
+            double bytes = (double)n * (24.0 * take + (src ? 0.0 : 8.0) + (rst ? 24.0 : 0.0));
+            if (rst) bytes += 8.0 * n + 8.0 * fu.M * fu.M;
+            if (pro) bytes += 16.0 * n + 8.0 * fu.Nc * fu.Nc;
+            ProfScope ps(name, N, bytes);
+            k::jacobi_tile(s, N, dx2, inv, src, F, dst, take, error_dev, d_sign, fu.coarse, fu.Nc, fu.pt, fu.Fc, fu.M, fu.rt, fu.no_out);
+        } else if (plain_single) {
             // one bare sweep of a large grid: the one-row-per-block pair kernel is the faster of the two
             // (5.1 vs 4.5 TB/s at N = 8192; same bits) -- there is nothing to fuse and no row history to amortise
             ProfScope ps("jacobi_pair", N, (double)n * 24.0);
@@ -904,6 +919,12 @@ void mg_smooth_restrict_f32(int N, double L, const float *U_in, float *U_out, fl
     const double dx2 = spacing_sq(N, L);
     const size_t n = (size_t)N * N;
     if (k::stream_fusable(N) && rt.fusable) {
+        if (c.smoother == SMOOTHER_STREAM && k::tile_wanted(N) && step <= k::tile_max_steps()) {  // small levels: mg_tile_impl.h
+            ProfScope ps("jacobi_tile_f32<zero,res,restrict>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
+            k::jacobi_tile_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, -1, nullptr, 0, nullptr, F_c, M,
+                               &rt, false);
+            return;
+        }
         ProfScope ps("jacobi_stream_f32<zero,res,restrict>", N, (double)n * (12.0 * step + 4.0 + 12.0 + 4.0) + 4.0 * M * M);
         k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), nullptr, F, U_out, step, error_dev, nullptr, 0, nullptr, F_c,
                              M, &rt);
@@ -966,6 +987,12 @@ void prolong_smooth_f32_impl(int Nc, const float *U_c, int N, double L, const fl
                                  0, nullptr);
         }
         scratch_pool().put(tmp);
+        return;
+    }
+    if (!pre && !U_out_wide && c.smoother == SMOOTHER_STREAM && k::tile_wanted(N) && step <= k::tile_max_steps()) {  // small levels: mg_tile_impl.h
+        ProfScope ps("jacobi_tile_f32<prolong>", N, (double)n * (12.0 * step + 8.0) + 4.0 * Nc * Nc);
+        k::jacobi_tile_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, error_dev, +1, U_c, Nc, &pt, nullptr, 0, nullptr,
+                           false);
         return;
     }
     char name[48];

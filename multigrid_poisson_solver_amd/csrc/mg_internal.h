@@ -219,6 +219,16 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
                    // pre > 0 (fused `1` node): `in` is not read, it is recomputed as `pre` sweeps from zero on F;
                    // no_out (fused `-1` node): the smoothed field is not stored (its `1` node will recompute it)
                    int pre = 0, bool no_out = false);
+// register-tile fused nodes of the small levels (mg_tile.hip / mg_tile_f32.hip): one launch = level 0 (zero | in | in +
+// P(coarse)), `steps` sweeps, the error norm, optionally the d_sign-ed residual restricted into Fc; whole grid only
+bool tile_wanted(int N);      // MG_TILE_MIN_N <= N <= MG_TILE_MAX_N
+int  tile_max_steps();
+void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out, int steps,
+                 double *err_out, int d_sign, const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
+                 const RestrictTable *rt, bool no_out);
+void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
+                     double *err_out, int d_sign, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
+                     const RestrictTable *rt, bool no_out);
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);

@@ -1,0 +1,420 @@
+// mg_tile_impl.h -- the fused node kernels of the SMALL levels (64 < N <= ~1024): a 2-D tile held in registers.
+//
+// The wave-streaming smoother (mg_stream_impl.h) is built for levels that do not fit the caches: a wave marches down
+// its column strip row by row through a software pipeline.  On a small level that march IS the launch: a dozen rows
+// of pipeline fill and drain at ~0.44 us per row step, a prologue of two dependent memory round trips, ~10 us per
+// launch whatever the bytes (profiles/r02_vcycle_levels.txt: 8 launches of 9.7-17.4 us for the levels 128...1024 of a
+// V-cycle, 240 of them in a W-cycle).  Here the same node is laid out the other way round:
+//
+//   * a workgroup owns a tile of TY x TX points and holds the window own +- HALO (HALO = S + 1 rows and columns: the
+//     halo is recomputed redundantly, never exchanged between workgroups) ENTIRELY IN REGISTERS: lane = column (64
+//     columns per window), wave w = RPW consecutive rows, one value per lane and row;
+//   * a sweep updates all rows of the window at once: the north/south neighbours of a row are the wave's own
+//     registers, except for the first and the last row of its block, which come from the neighbouring waves through
+//     two rows of LDS (double-buffered: one barrier per sweep); east/west neighbours are the adjacent lanes (DPP
+//     wave_shr/shl:1, as in the streaming kernel);
+//   * all loads of the node (F, U, the coarse rows of the fused prolongation, the per-row and per-column transfer
+//     tables) are issued up front in one batch -- one memory round trip, then S barrier-separated sweeps of a few
+//     hundred cycles each;
+//   * the fused input and output stages are those of the streaming kernel: level 0 = zero | U | U + P(coarse)
+//     (src/MG_solver_CPU.cpp:256 | - | :354 + :368), then the sweeps (:587-599), the error norm (:607-622), and
+//     optionally the signed residual restricted into the next level's F (:268, :277-280, :287).
+//
+// Every point is evaluated with the expressions of the streaming kernel (mg_lane_ops.h, mg_divconst.h: the reference's
+// association order under -ffp-contract=off), so the arrays are bit-identical to it and to the reference; a halo
+// point computed by two tiles gets the same bits twice.  Norm partials are summed in another order (per wave, then
+// the fixed-order finish of mg_kernels.hip): the scalar agrees to rounding, as between any two kernels here.
+//
+// Kernel source for both field types (MG_REAL = double: mg_tile.hip; float: mg_tile_f32.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "mg_divconst.h"
+#include "mg_internal.h"
+#include "mg_lane_ops.h"
+
+#if !defined(MG_REAL) || !defined(MG_REAL_NS)
+#error "define MG_REAL (double|float) and MG_REAL_NS (f64|f32) before including mg_tile_impl.h"
+#endif
+
+namespace mg {
+namespace k {
+namespace MG_REAL_NS {
+namespace tile {
+
+typedef MG_REAL real_t;
+
+enum InMode { T_ZERO = 0, T_LOAD = 1, T_PROLONG = 2 };
+
+struct TileParams {
+    int N;
+    real_t dx2, inv;
+    const real_t *in;   // T_ZERO: unused
+    const real_t *F;
+    real_t *out;
+    int no_out;         // the smoothed U is not stored
+    int d_sign;
+    double *part;       // nullptr: no error norm; else one partial per wave
+    int tiles_x, n_blocks;
+    // T_PROLONG: coarse grid and the host-built tables of doProlongation
+    const real_t *coarse;
+    int Nc;
+    const int *p_orow, *p_ocol;
+    const real_t *p_rhi, *p_rlo, *p_chi, *p_clo;
+    real_t c_dx, c_dx_rcp;
+    // RESTRICT: next level's F and the host-built tables of doRestriction
+    real_t *Fc;
+    int M;
+    const int *r_inv;   // [N] fine index -> interior coarse index whose lower-left sample it is, or -1
+    const real_t *r_w;  // [M] weights by coarse index
+    const real_t *r_wf; // [N] r_w[r_inv[x]] by fine index (0 where r_inv < 0)
+};
+
+// window rows/columns beyond the owned tile, per side.  Level s of a point is valid when the point lies at least s rows
+// and columns inside the window (every sweep loses one ring; from the zero field level 1 needs no neighbours, so one
+// ring less is lost).  The error norm needs the residual on the owned tile (level S one ring beyond it), the fused
+// restriction the residual one row and column beyond the tile (level S two rings beyond it).
+template <int S, int IN, bool RESTRICT>
+struct Geom {
+    static constexpr int HALO = S + 1 + ((RESTRICT && IN != T_ZERO) ? 1 : 0);
+    static constexpr int TX = 64 - 2 * HALO;
+};
+
+template <int S, int IN, bool RESTRICT, int RPW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
+{
+    constexpr int HALO = Geom<S, IN, RESTRICT>::HALO;
+    constexpr int RH = RPW * WAVES;       // rows of the window
+    constexpr int TY = RH - 2 * HALO;     // rows the tile owns
+    constexpr int TX = Geom<S, IN, RESTRICT>::TX;
+    static_assert(TY >= 2 && TX >= 2 && RPW >= 2 && RPW <= 32, "window too small for its halo");
+    // first and last row of every wave's block, of the level being swept; [parity]: the next exchange writes the other
+    // half while a slow wave may still read this one (one barrier per exchange)
+    __shared__ real_t xch[2][WAVES][2][64];
+
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles (a band of rows),
+    // so the halo re-reads of neighbouring tiles hit its L2.  Speed only, never correctness.
+    const int per_xcd = (p.n_blocks + 7) >> 3;
+    const int tile_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile_id >= p.n_blocks) return;   // (the whole workgroup: no barrier is left waiting)
+    const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int N = p.N;
+    const int oy0 = tile_y * TY, oy1 = oy0 + TY < N ? oy0 + TY : N;
+    const int ox0 = tile_x * TX, ox1 = ox0 + TX < N ? ox0 + TX : N;
+    const int x = ox0 - HALO + lane;        // this lane's column
+    const int yb = oy0 - HALO + wave * RPW; // first row of this wave's block
+
+    // ---- column state (lane constants)
+    const bool col_edge = x <= 0 || x >= N - 1;       // rim column, or outside the grid
+    const bool lane_owns = x >= ox0 && x < ox1;
+    const int xc = x < 0 ? 0 : (x < N ? x : N - 1);   // loads are unconditional: columns/rows outside the grid are clamped to a
+                                                      // valid address; what they return never reaches a stored point
+    // rim points keep their value: the update is U + q*t with q = 0.25 inside and 0 on the rim (row: AND with a mask)
+    const real_t qc = col_edge ? real_t(0.0) : real_t(0.25);
+    const real_t dx2 = p.dx2, inv = p.inv;
+    const bool want_res = RESTRICT || p.part != nullptr;
+
+    auto row_y = [&](int j) { return yb + j; };
+    auto row_clamped = [&](int j) { const int y = yb + j; return y < 0 ? 0 : (y < N ? y : N - 1); };
+    auto row_inner = [&](int j) { return ((unsigned)(yb + j - 1) < (unsigned)(N - 2)) ? -1 : 0; };  // 0 on the rim rows and outside
+    auto row_owned = [&](int j) { return (unsigned)(yb + j - oy0) < (unsigned)(oy1 - oy0); };
+
+    // ---- every load of the node, issued in one batch ---------------------------------------------------------------
+    real_t f[RPW], v[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) f[j] = p.F[(size_t)row_clamped(j) * N + xc];
+    if constexpr (IN != T_ZERO) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) v[j] = p.in[(size_t)row_clamped(j) * N + xc];
+    }
+    // wave-uniform per-row table entries ride in one register per table, row j of the block in lane j (v_readlane)
+    const int yl = yb + (lane < RPW ? lane : RPW - 1);
+    const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);
+    int t_own = 0;
+    real_t t_rhi = 0, t_rlo = 0, pc_hi = 0, pc_lo = 0;
+    real_t ca[RPW], cb[RPW], c0a = 0, c0b = 0;
+    int own[RPW];
+    if constexpr (IN == T_PROLONG) {
+        t_own = p.p_orow[ylc];
+        t_rhi = p.p_rhi[ylc];
+        t_rlo = p.p_rlo[ylc];
+        const int cj = p.p_ocol[xc];
+        pc_hi = p.p_chi[xc];
+        pc_lo = p.p_clo[xc];
+        const int last = p.Nc - 1;
+        const int cj1 = cj + 1 < last ? cj + 1 : last;
+        // coarse rows owner and owner + 1 of every fine row (the owner advances by at most one per fine row, host-checked:
+        // ProlongTable::fusable): row (owner + 1) travels with its fine row, row owner(first row) once
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            own[j] = lane_value(t_own, j);
+            const int up = own[j] + 1 < last ? own[j] + 1 : last;
+            const real_t *crow = p.coarse + (size_t)up * p.Nc;
+            ca[j] = crow[cj];
+            cb[j] = crow[cj1];
+        }
+        const real_t *crow0 = p.coarse + (size_t)own[0] * p.Nc;
+        c0a = crow0[cj];
+        c0b = crow0[cj1];
+    }
+    int t_rc = -1, rc_col = -1;
+    real_t t_rw = 0, rw_a = 0, rw_b = 0;
+    if constexpr (RESTRICT) {
+        const bool ok = yl >= oy0 && yl < oy1 && lane < RPW;   // rows outside the tile sample nothing
+        const int rc = p.r_inv[ylc];
+        t_rw = p.r_wf[ylc];
+        t_rc = ok ? rc : -1;
+        if (lane_owns) {
+            rc_col = p.r_inv[x];
+            if (rc_col >= 0) {
+                rw_a = p.r_w[rc_col];
+                rw_b = real_t(1.0) - rw_a;  // src/MG_solver_CPU.cpp:665
+            }
+        }
+    }
+
+    // ---- level 0 -------------------------------------------------------------------------------------------------
+    if constexpr (IN == T_PROLONG) {
+        // U + P(coarse): doProlongation :700 as a gather, then doGridAddition :569 -- the streaming kernel's expressions:
+        // hA / hB = (c1*(c2x-f_x) + c2*(f_x-c1x)) of the coarse rows owner / owner + 1 at this lane's column
+        real_t hA = 0, hB = c0a * pc_hi + c0b * pc_lo;
+        int c_row = own[0] - 1;
+        const real_t c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            if (own[j] != c_row) {  // wave-uniform: the owner row advanced by one
+                hA = hB;
+                c_row = own[j];
+                hB = ca[j] * pc_hi + cb[j] * pc_lo;
+            }
+            const real_t own_yh = lane_value(t_rhi, j), own_yl = lane_value(t_rlo, j);
+            const real_t num = hA * own_yh + hB * own_yl;
+            const real_t pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
+            v[j] = v[j] + pv;
+        }
+    }
+
+    // first / last row of the neighbouring waves' blocks, of the level in v[]
+    int xb = 0;
+    auto exchange = [&](const real_t &first, const real_t &last, real_t &below, real_t &above) {
+        xch[xb][wave][0][lane] = first;
+        xch[xb][wave][1][lane] = last;
+        __syncthreads();
+        below = wave > 0 ? xch[xb][wave - 1][1][lane] : real_t(0.0);
+        above = wave < WAVES - 1 ? xch[xb][wave + 1][0][lane] : real_t(0.0);
+        xb ^= 1;
+    };
+
+    // ---- S sweeps (src/MG_solver_CPU.cpp:587-599), all rows of the window at once -----------------------------------
+#pragma unroll
+    for (int s = 1; s <= S; ++s) {
+        if (IN == T_ZERO && s == 1) {
+            // the first sweep from the zero field: every neighbour and the point itself are +0, so the sum, `- 4*U` and
+            // `U +` of the general expression are exact no-ops -- the same bits without them
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const real_t t4 = real_t(0.0) - dx2 * f[j];
+                v[j] = fused_mul_add(hi_bits_and(qc, row_inner(j)), t4, real_t(0.0));
+            }
+            continue;
+        }
+        real_t below, above;
+        exchange(v[0], v[RPW - 1], below, above);
+        real_t o[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const real_t c = v[j];
+            const real_t so = j > 0 ? v[j > 0 ? j - 1 : 0] : below;
+            const real_t nw = j < RPW - 1 ? v[j < RPW - 1 ? j + 1 : 0] : above;
+            const real_t w = from_lane_below(c), e = from_lane_above(c);
+            // :590  U += 0.25*(U[i+1]+U[i-1]+U[j+1]+U[j-1] - 4U - dx^2 F), fused exactly as in the streaming kernel
+            const real_t t4 = minus4(nw + so + e + w, c) - dx2 * f[j];
+            o[j] = fused_mul_add(hi_bits_and(qc, row_inner(j)), t4, c);
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) v[j] = o[j];
+    }
+
+    // ---- the smoothed U ---------------------------------------------------------------------------------------------
+    if (!p.no_out && lane_owns) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+            if (row_owned(j)) p.out[(size_t)row_y(j) * N + x] = v[j];
+    }
+
+    // ---- residual (:560), error sums (:610/:617), restriction (:656-678) -------------------------------------------
+    if (want_res) {
+        real_t below, above;
+        exchange(v[0], v[RPW - 1], below, above);
+        real_t d[RPW];
+        double acc = 0.0;
+        const real_t ms = col_edge ? real_t(0.0) : (p.d_sign < 0 ? real_t(-1.0) : real_t(1.0));
+        // error norm: interior points with (row + col) even, each counted by the lane and tile that own it
+        const bool mine = lane_owns && !col_edge;
+        const int nm_even = (mine && ((x + yb) & 1) == 0) ? -1 : 0, nm_odd = (mine && ((x + yb) & 1) != 0) ? -1 : 0;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const real_t c = v[j];
+            const real_t so = j > 0 ? v[j > 0 ? j - 1 : 0] : below;
+            const real_t nw = j < RPW - 1 ? v[j < RPW - 1 ? j + 1 : 0] : above;
+            const real_t w = from_lane_below(c), e = from_lane_above(c);
+            const real_t r = inv * minus4(nw + so + e + w, c) - f[j];
+            const int inner = row_inner(j);
+            if constexpr (RESTRICT) d[j] = r * hi_bits_and(ms, inner);  // sign flip :277-280 and the zero rim in one exact product
+            const int am = ((j & 1) ? nm_odd : nm_even) & (row_owned(j) ? inner : 0);
+            acc += fabs(bits_and((double)r, am));
+        }
+        if (p.part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            if (lane == 0) p.part[(size_t)tile_id * WAVES + wave] = acc;
+        }
+        if constexpr (RESTRICT) {
+            // the row after the block's last one: the next wave's first
+            real_t d_next, unused;
+            exchange(d[0], d[RPW - 1], unused, d_next);
+            (void)unused;
+            const bool first_col_lane = lane_owns && x == 0, last_col_lane = lane_owns && x == N - 1;
+            // the rim of the next level's F is zero (doRestriction's memset, :651): rim rows by the tiles that hold fine
+            // rows 0 and N-1, rim columns by the lanes that own fine columns 0 and N-1 alongside every coarse row
+            if (wave == 0) {
+                for (int edge = 0; edge < 2; ++edge) {
+                    if (edge == 0 ? (oy0 != 0) : (oy1 != N)) continue;
+                    real_t *row = p.Fc + (size_t)(edge == 0 ? 0 : p.M - 1) * p.M;
+                    if (rc_col >= 0) row[rc_col] = 0.0;
+                    if (first_col_lane) row[0] = 0.0;
+                    if (last_col_lane) row[p.M - 1] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int rc_row = lane_value(t_rc, j);   // coarse row whose lower-left sample lies in fine row j of the block, or -1
+                if (rc_row < 0) continue;
+                const real_t wc = lane_value(t_rw, j), wd = real_t(1.0) - wc;  // c, d of :664-666
+                const real_t u0 = d[j], u2 = j < RPW - 1 ? d[j < RPW - 1 ? j + 1 : 0] : d_next;
+                const real_t u1 = from_lane_above(u0), u3 = from_lane_above(u2);
+                // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
+                const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
+                real_t *crow = p.Fc + (size_t)rc_row * p.M;
+                if (rc_col >= 0) crow[rc_col] = vc;
+                if (first_col_lane) crow[0] = 0.0;
+                if (last_col_lane) crow[p.M - 1] = 0.0;
+            }
+        }
+    }
+}
+
+// geometry of one instantiation, for the launcher
+template <int S, int IN, bool RESTRICT, int RPW, int WAVES>
+void launch_tile(hipStream_t s, TileParams p, double *err_out)
+{
+    constexpr int HALO = Geom<S, IN, RESTRICT>::HALO, TY = RPW * WAVES - 2 * HALO, TX = Geom<S, IN, RESTRICT>::TX;
+    const int N = p.N;
+    p.tiles_x = (N + TX - 1) / TX;
+    const int tiles_y = (N + TY - 1) / TY;
+    p.n_blocks = p.tiles_x * tiles_y;
+    p.part = nullptr;
+    const size_t n_part = (size_t)p.n_blocks * WAVES;
+    if (err_out) {
+        p.part = norm_partials(n_part);  // every wave of every tile writes its slot
+        if (!p.part) return;
+    }
+    const int grid = ((p.n_blocks + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_jacobi_tile<S, IN, RESTRICT, RPW, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p);
+    if (err_out) norm_finish(s, p.part, n_part, N, err_out);
+}
+
+// rows per wave: few for the smallest levels (more, shorter workgroups: the launch is pure latency), more where the
+// redundant halo rows start to cost (TY = 4 * RPW - 2 * HALO rows owned of 4 * RPW computed)
+template <int S, int IN, bool RESTRICT>
+void launch_geom(hipStream_t s, const TileParams &p, double *err_out)
+{
+    static const int forced = [] { const char *e = getenv("MG_TILE_RPW"); return e ? atoi(e) : 0; }();
+    constexpr int HALO = Geom<S, IN, RESTRICT>::HALO;
+    const int rpw = forced ? forced : (p.N <= 256 ? 6 : 12);
+    if (rpw <= 6 && 4 * 6 - 2 * HALO >= 8) launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out);
+    else launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out);
+}
+
+template <int S>
+void launch_steps(hipStream_t s, const TileParams &p, double *err_out)
+{
+    const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
+    if (restrict_out) {
+        if (zero) launch_geom<S, T_ZERO, true>(s, p, err_out);
+        else launch_geom<S, T_LOAD, true>(s, p, err_out);
+    } else if (prolong_in) {
+        launch_geom<S, T_PROLONG, false>(s, p, err_out);
+    } else {
+        if (zero) launch_geom<S, T_ZERO, false>(s, p, err_out);
+        else launch_geom<S, T_LOAD, false>(s, p, err_out);
+    }
+}
+
+struct Tables {
+    const int *p_orow = nullptr, *p_ocol = nullptr;
+    const real_t *p_rhi = nullptr, *p_rlo = nullptr, *p_chi = nullptr, *p_clo = nullptr;
+    real_t c_dx = 0, c_dx_rcp = 0;
+    const int *r_inv = nullptr;
+    const real_t *r_w = nullptr, *r_wf = nullptr;
+};
+
+constexpr int MAX_S = 4;
+
+// one fused node on the whole grid: same contract as the streaming kernel's entry point without row windows, without a
+// stored residual and without the recomputing form (the caller routes those to the streaming kernel)
+inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps, double *err_out,
+                int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M, const Tables &tb, bool no_out)
+{
+    if (steps < 1 || steps > MAX_S || N < 8) {
+        fail(MG_ERR_ARG, "jacobi_tile: %d sweeps on N=%d (1..%d sweeps, N >= 8)", steps, N, MAX_S);
+        return;
+    }
+    if (coarse && Fc) {
+        fail(MG_ERR_ARG, "jacobi_tile: a node either prolongs or restricts");
+        return;
+    }
+    TileParams p = {};
+    p.N = N;
+    p.dx2 = dx2;
+    p.inv = inv;
+    p.in = in;
+    p.F = F;
+    p.out = out;
+    p.no_out = no_out ? 1 : 0;
+    p.d_sign = d_sign;
+    if (coarse) {
+        p.coarse = coarse;
+        p.Nc = Nc;
+        p.p_orow = tb.p_orow;
+        p.p_ocol = tb.p_ocol;
+        p.p_rhi = tb.p_rhi;
+        p.p_rlo = tb.p_rlo;
+        p.p_chi = tb.p_chi;
+        p.p_clo = tb.p_clo;
+        p.c_dx = tb.c_dx;
+        p.c_dx_rcp = tb.c_dx_rcp;
+    }
+    if (Fc) {
+        p.Fc = Fc;
+        p.M = M;
+        p.r_inv = tb.r_inv;
+        p.r_w = tb.r_w;
+        p.r_wf = tb.r_wf;
+    }
+    switch (steps) {
+        case 1: launch_steps<1>(s, p, err_out); break;
+        case 2: launch_steps<2>(s, p, err_out); break;
+        case 3: launch_steps<3>(s, p, err_out); break;
+        default: launch_steps<4>(s, p, err_out); break;
+    }
+}
+
+}  // namespace tile
+}  // namespace MG_REAL_NS
+}  // namespace k
+}  // namespace mg

@@ -337,6 +337,48 @@ def test_product_thresholds_against_the_oracle_and_against_the_test_thresholds(m
     plan.close()
 
 
+def test_product_thresholds_on_the_small_and_medium_levels(mg, oracle, tmp_path):
+    """The same child process (the library's own thresholds: register-tile kernel on the levels 65...1024, streaming
+    kernel in its store/re-read form on 2048, recomputing pair from 4096 on) at sizes the oracle finishes in seconds:
+    V- and W-cycles with 1...4 sweeps per node, a hierarchy that is not a power of two, and the fp32 cycle of the mixed
+    mode against the numpy restatement -- the final U through the 128-bit checksum, every smoothing error."""
+    import json
+    import _synth
+    import _oracle_f32 as o32
+    specs = ["V:1024:3", "V:2048:3", "W:512:3", "V:1024:1", "V:1024:2", "V:1024:4", "W:256:2", "V:1448:3", "V:704:3", "MV:1024:3", "MV:512:2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("MG_RECOMPUTE_MIN_N", "MG_NT_MIN_N", "MG_F32_COLS4_MIN_N")}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_defaults_worker.py")] + specs, env=env,
+                         capture_output=True, text=True, timeout=900)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
+    assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-3000:]
+    child = json.loads(line[0][len("DEFAULTS_WORKER "):])
+    for spec in specs:
+        kind, N, steps = spec.split(":")
+        N, steps = int(N), int(steps)
+        path = str(tmp_path / f"{kind}{N}_{steps}.txt")
+        (mg.write_wcycle_file if kind == "W" else mg.write_vcycle_file)(path, N, 8, steps, 1e-7)
+        got = child[spec]
+        assert got["status"] == 0, spec
+        if kind == "MV":
+            toks = open(path).read().split()
+            sizes, n = [], N
+            while n >= 8:
+                sizes.append(n)
+                n //= 2
+            U32, recs = o32.run_cycle_tokens(mg, oracle, oracle.getSource(N), 1.0, steps, sizes, toks[7:])
+            assert tuple(got["sum"]) == _synth.checksum(U32.astype(np.float64)), f"{spec}: fp32 result differs from the numpy restatement"
+            for g, w in zip(got["errors"], recs):
+                assert g == pytest.approx(w[2], rel=1e-10, abs=1e-300), spec
+            continue
+        want = oracle.run_cycle_file(path, want_report=False)
+        assert want["status"] == 0
+        assert tuple(got["sum"]) == _synth.checksum(want["U"]), f"{spec}: final U differs from the oracle's"
+        assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+        assert len(got["errors"]) == len(want["records"])
+        for g, w in zip(got["errors"], want["records"]):
+            assert g == pytest.approx(w[3], rel=1e-12, abs=1e-300), spec
+
+
 @pytest.mark.parametrize("kind,N,n_min", [("V", 88, 8), ("V", 1448, 8), ("W", 176, 8), ("V", 104, 8), ("V", 256, 16), ("V", 120, 8)])
 def test_cycles_whose_coarsest_level_has_65_to_256_points(mg, oracle, tmp_path, kind, N, n_min):
     """Hierarchies that do not end on an 8 x 8 grid (the weak-scaling grids 11520 and 23040 end on 11 x 11;
