@@ -73,16 +73,17 @@ def vcycle_algorithmic_bytes(sizes, nu1, nu2):
 RECOMPUTE_MIN_N = int(os.environ.get("MG_RECOMPUTE_MIN_N", "4096"))  # the library's default (mg_abi.cpp: recompute_available)
 
 
-def vcycle_compulsory_bytes(sizes, recompute=True):
+def vcycle_compulsory_bytes(sizes, recompute=True, visits=None):
     """HBM bytes one V-cycle of the FUSED driver cannot avoid: per level one `-1` launch (F in, U out, coarse F
     out: 16 n + 8 m) and one `1` launch (U, F, coarse U in, U out: 24 n + 8 m); from N = 4096 on the pair neither
     writes nor re-reads the pre-smoothed U (the `1` node recomputes it): 8 n + 8 m and 16 n + 8 m.  The coarse tail
     (N <= 64) lives in LDS and is not counted."""
     total = 0.0
-    for a, b in zip(sizes[:-1], sizes[1:]):
+    for l, (a, b) in enumerate(zip(sizes[:-1], sizes[1:])):
         if a <= 64:
             break
-        total += (24.0 if recompute and a >= RECOMPUTE_MIN_N else 40.0) * a * a + 16.0 * b * b
+        # (visits: W-cycle, every visit of a level pair moves its bytes again)
+        total += (visits[l] if visits else 1) * ((24.0 if recompute and a >= RECOMPUTE_MIN_N else 40.0) * a * a + 16.0 * b * b)
     return total
 
 
@@ -134,12 +135,18 @@ def compulsory_bytes(kernel_family, N):
         return (8.0 if "noU" in kernel_family else 16.0) * n + 8.0 * (N // 2) ** 2
     if "prolong" in kernel_family:    # pre3: the pre-smoothed field is recomputed (3 sweeps from zero), not read
         return (16.0 if "pre" in kernel_family else 24.0) * n + 8.0 * (N // 2) ** 2
-    if "jacobi_stream" in kernel_family or "jacobi_pair" in kernel_family:
+    if "jacobi_stream" in kernel_family or "jacobi_pair" in kernel_family or "jacobi_tile" in kernel_family:
         return (16.0 if "zero" in kernel_family else 24.0) * n
     return None
 
 
-def cpu_baseline(tmp, N, n_min, nu, write_vcycle_file):
+def level_visits(sizes, cycle):
+    """How often a level's `-1` / `1` node pair runs in one cycle: once per level in a V-cycle; in the W-cycle of the shipped
+    src/Wcycle.txt recursion level l >= 1 runs 2^l times."""
+    return [1] * len(sizes) if cycle == "V" else [1] + [2 ** l for l in range(1, len(sizes))]
+
+
+def cpu_baseline(tmp, N, n_min, nu, write_vcycle_file, cycle="V"):
     """The reference's own operators (oracle/_ref/libmgref*.so, built from /root/reference by oracle/Makefile)
     -- or, when that build is absent, the oracle's restatement -- timed on this host's cores in the reference's
     own window (src/MG_solver_CPU.cpp:156..429).  BASELINE.md section 3: both builds (-O2 and the shipped
@@ -154,9 +161,10 @@ def cpu_baseline(tmp, N, n_min, nu, write_vcycle_file):
     kind = "reference" if have_ref else "port"
 
     def timed(n, threads, reps, makefile_flags=False):
-        path = os.path.join(tmp, f"cpu_Vcycle_{n}.txt")
+        path = os.path.join(tmp, f"cpu_{cycle}cycle_{n}.txt")
         write_vcycle_file(path, n, n_min, nu, 1e-7)
-        lups = sum(2 * nu * s * s for s in level_sizes(n, n_min)[:-1])
+        szs = level_sizes(n, n_min)
+        lups = sum(2 * nu * v * s * s for s, v in zip(szs[:-1], level_visits(szs, cycle)[:-1]))
         ops = None
         if have_ref:
             ops = _oracle.Reference(makefile_flags=makefile_flags)
@@ -172,12 +180,13 @@ def cpu_baseline(tmp, N, n_min, nu, write_vcycle_file):
         return {"N": n, "threads": threads, "reps": reps, "min_ms": round(min(ts), 2), "median_ms": round(statistics.median(ts), 2),
                 "value": round(lups / (min(ts) * 1e-3) / 1e6, 3), "unit": "MLUPS", "mg_error": err}
 
-    head = timed(N, cores, 3)
+    reps = 3 if cycle == "V" else 1   # (a W-cycle is 1.5x the sweeps of a V-cycle plus 2^k coarse solves: one run bounds the leg)
+    head = timed(N, cores, reps)
     if not head:
         return None
     out = {"value": head["value"], "unit": "MLUPS", "cores": cores, "kind": kind, "time_ms": head["min_ms"],
-           "median_ms": head["median_ms"], "reps": 3, "mg_error": head["mg_error"],
-           "sample": (f"V({nu},{nu})-cycle at N={N}^2, the reference's timed window, 3 runs (value = fastest), "
+           "median_ms": head["median_ms"], "reps": reps, "mg_error": head["mg_error"],
+           "sample": (f"{cycle}({nu},{nu})-cycle at N={N}^2, the reference's timed window, {reps} run{'s (value = fastest)' if reps > 1 else ''}, "
                       f"{'reference operators (oracle/_ref/libmgref.so, g++ -O2 -fopenmp)' if have_ref else 'oracle restatement (-O2)'}"
                       f", {cores} OpenMP threads"),
            "variants": {}}
@@ -257,6 +266,9 @@ def main():
                     help="which leg is the line's `value` (the other one is nested)")
     ap.add_argument("--mixed", action="store_true",
                     help="mixed-precision mode (fp32 cycle, fp64 source/result; NOT the headline metric, which is fp64)")
+    ap.add_argument("--refine", type=int, default=1,
+                    help="with --mixed: fp32 cycles per window, joined by the fp64 residual of the fp64 iterate and an fp64 correction "
+                         "(BASELINE.json configs[4]: fp32 smoothing / fp64 residual correction)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the row-slab/RCCL leg even with one rank (plumbing rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -283,19 +295,18 @@ def main():
     sizes = level_sizes(N, args.n_min)
     tmp = tempfile.mkdtemp(prefix="mgbench_")
     cyc = os.path.join(tmp, f"{args.cycle}cycle_{N}.txt")
-    if args.cycle == "V":
-        mg.write_vcycle_file(cyc, N, args.n_min, nu, 1e-7)
-        visits = [1] * len(sizes)
-    else:
-        mg.write_wcycle_file(cyc, N, args.n_min, nu, 1e-7)
-        # level l >= 1 is smoothed by 2^l '-1' nodes and 2^l '1' nodes (shipped src/Wcycle.txt recursion)
-        visits = [1] + [2 ** l for l in range(1, len(sizes))]
+    write_cycle = mg.write_vcycle_file if args.cycle == "V" else mg.write_wcycle_file
+    write_cycle(cyc, N, args.n_min, nu, 1e-7)
+    visits = level_visits(sizes, args.cycle)
     # lattice updates of one step: (nu1+nu2) * sum over smoothed levels of n_l (x visits for W)
     lups = sum(2 * nu * v * s * s for s, v in zip(sizes[:-1], visits[:-1]))
-    algo_bytes = vcycle_algorithmic_bytes(sizes, nu, nu) if args.cycle == "V" else None
+    # the W-cycle's algorithmic bytes are the per-level term weighted by the level's visits
+    algo_bytes = sum(v * ((8 + 24 * nu + 24 + 8 + 16 + 24 * nu) * a * a + 16.0 * b * b) for v, a, b in zip(visits, sizes[:-1], sizes[1:]))
 
+    refine = max(1, args.refine) if args.mixed else 1
     plan = mg.CyclePlan(cyc, fused=(args.mode != "unfused"), graph=(args.mode == "graph"), report=False, error=False,
-                        mixed=args.mixed)
+                        mixed=args.mixed, refinement=refine)
+    lups *= refine   # a window of the refinement runs the cycle file `refine` times (fp32), joined by an fp64 residual + correction
     # ---- timed region: exactly K steps, bracketed by synchronisation on both sides ----
     ms_per_step, r, prof = time_cycle(mg, plan, args.steps, max(args.warmup, 2 if args.mode == "graph" else 0), profile_min_N=N)
     dev_ms = r["device_ms"]
@@ -341,7 +352,9 @@ def main():
         "vs_baseline": None, "dtype": "f32" if args.mixed else "f64", "data": "synthetic",
         "config": {"workload": f"{args.cycle}({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'}, {len(sizes)} levels to N={sizes[-1]}, "
                                f"red-black GS(1e-7) coarse solve, cycle-file driver ({args.mode}, {args.smoother} smoother: "
-                               f"temporally blocked wave-streaming kernels, halos in registers via DPP lane shifts, no LDS tiles)",
+                               f"temporally blocked wave-streaming kernels on the large levels, register-tile kernels on the levels 65..1024, "
+                               f"one-workgroup LDS kernel below; halos recomputed, neighbours via DPP lane shifts)"
+                               + (f", {refine} fp32 cycles per window joined by fp64 residual + correction" if refine > 1 else ""),
                    "N": N, "levels": len(sizes), "cycle_file": os.path.basename(cyc)},
         "device_ms_per_step": round(dev_ms, 4),
         "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1),
@@ -350,7 +363,10 @@ def main():
         "kernels": kernels[:8],
     }
     if algo_bytes:
-        cb = vcycle_compulsory_bytes(sizes) * elem
+        cb = vcycle_compulsory_bytes(sizes, visits=visits) * elem * refine
+        if refine > 1:   # per joint: fp64 iterate + fp64 source read, fp32 source written; fp32 correction read, fp64 iterate read + written
+            cb += (refine - 1) * (8 + 8 + 4 + 4 + 8 + 8) * float(N) * N
+        algo_bytes *= refine
         out["cycle_roofline"] = {"compulsory_bytes": cb, "achieved": round(cb / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(cb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "algorithmic_equiv": {"bytes": algo_bytes, "GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1)}}
@@ -420,7 +436,7 @@ def main():
         out["config"]["N"] = STRONG_N
 
     if not args.no_cpu:
-        base = cpu_baseline(tmp, N, args.n_min, nu, mg.write_vcycle_file)
+        base = cpu_baseline(tmp, N, args.n_min, nu, write_cycle, args.cycle)
         if base:
             out["cpu_baseline"] = base
     mg.finalize()

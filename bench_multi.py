@@ -50,7 +50,9 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
     mg.write_vcycle_file(cyc, N, args.n_min, nu, 1e-7)
     lups = sum(2 * nu * s * s for s in sizes[:-1])
     collapse_N = int(os.environ.get("MG_COLLAPSE_N", "1024"))
-    plan = mg.SlabPlan(cyc, world, rank if world > 1 else -1, collapse_N, mixed=args.mixed)
+    refine = max(1, getattr(args, "refine", 1)) if args.mixed else 1   # configs[4]: fp32 cycles joined by fp64 residual + correction
+    lups *= refine
+    plan = mg.SlabPlan(cyc, world, rank if world > 1 else -1, collapse_N, mixed=args.mixed, refinement=refine)
     for _ in range(max(1, args.warmup)):
         r = plan.execute()
         assert r["status"] == 0, r
@@ -116,7 +118,8 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((k0["compulsory_GBs"] or 0.0) / HBM_PEAK_GBS, 4),
                 "traffic": None, "avg_ms": k0["avg_ms"], "launches": k0["launches"],
                 "algorithmic_equiv": {"GBs": k0["algorithmic_equiv_GBs"]}}
-    cb = vcycle_compulsory_bytes(sizes) * elem
+    refine_text = f"{refine} fp32 cycles per window joined by the fp64 residual of the fp64 iterate and an fp64 correction, " if refine > 1 else ""
+    cb = vcycle_compulsory_bytes(sizes) * elem * refine + (refine - 1) * 40.0 * N * N   # (joint: 8+8+4 B/pt residual, 4+8+8 B/pt correction)
     gbs = cb / (ms_per_step * 1e-3) / 1e9
     return {
         "N": N, "value": round(lups / (ms_per_step * 1e-3) / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps,
@@ -124,7 +127,7 @@ def run_leg(mg, args, rank, world, N, rehearsal, tmp):
         "ms_per_step_ranks": {"min": round(min(per_rank_ms), 4), "max": round(max(per_rank_ms), 4),
                               "all": [round(v, 4) for v in per_rank_ms]},
         "workload": f"V({nu},{nu})-cycle N={N}^2 {'fp32 cycle (mixed mode)' if args.mixed else 'fp64'} ({N * N // world} points per GPU), "
-                    f"{len(sizes)} levels, {world} row slabs, communication-avoiding schedule (F halos recomputed, the pre-smoothed U of the levels >= 4096 recomputed instead of "
+                    f"{len(sizes)} levels, {refine_text}{world} row slabs, communication-avoiding schedule (F halos recomputed, the pre-smoothed U of the levels >= 4096 recomputed instead of "
                     f"stored/re-read/exchanged, ONE RCCL group per cycle on a second stream: collapse all-gather + one U halo), levels N<={collapse_N} replicated on every rank",
         "levels": len(sizes), "fine_dof_per_s": round(N * N / (ms_per_step * 1e-3), 1), "mg_error": r["mg_error"],
         "roofline": roof, "kernels": kernels[:6],

@@ -52,6 +52,10 @@ struct ProlongTable {
     double c_dx = 0.0;
     bool fusable = false;  // every fine index owned, owners advance by <= 1 per fine index
     bool fusable4 = false; // ... and 4 aligned fine columns span at most 3 coarse cells (4 columns per lane, fp32)
+    // owner_row[k] == owner_col[k] == min(k*(N-1)/(M-1), N-2) in integer arithmetic for every fine index k (checked entry
+    // by entry against the tables built from the reference's ceil() expressions; M <= 4096): a kernel may then form the
+    // owner -- an ADDRESS ingredient -- itself instead of waiting for a table load before it can issue its coarse loads
+    bool closed_form = false;
 };
 
 // a window of grid rows held in a local array: rows [base, base+rows) of the global grid

@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace mg {
 namespace k {
 
@@ -66,6 +68,27 @@ __device__ __forceinline__ float bits_and(float v, int mask) { return __int_as_f
 // the same for a constant whose low 32 bits are zero (0.25, +-1.0): one AND on the high dword
 __device__ __forceinline__ double hi_bits_and(double v, int mask) { return __hiloint2double(__double2hiint(v) & mask, 0); }
 __device__ __forceinline__ float hi_bits_and(float v, int mask) { return __int_as_float(__float_as_int(v) & mask); }
+
+// sum of a value over the 64 lanes of the wave, through DPP only (no LDS crossbar: the shuffle-based tree costs a lone
+// wave ~100 cycles per step): prefix sums inside each row of 16 lanes, then rows 1 and 3 add the total of the row below
+// them (row_bcast:15), then rows 2-3 add lane 31's (row_bcast:31); lane 63 holds (r0 + r1) + (r2 + r3)
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    auto shr = [](double x, auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true));
+    };
+    v += shr(v, std::integral_constant<int, 0x111>{});
+    v += shr(v, std::integral_constant<int, 0x112>{});
+    v += shr(v, std::integral_constant<int, 0x114>{});
+    v += shr(v, std::integral_constant<int, 0x118>{});
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, false));
+    v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x143, 0xc, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x143, 0xc, 0xf, false));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 
 }  // namespace k
 }  // namespace mg

@@ -163,6 +163,12 @@ const ProlongTable &prolong_table(int N, int M)
         t.col_lo_f = upload(clf);
         t.c_dx = 1.0 / (double)(N - 1);
         t.fusable = fusable;
+        t.closed_form = fusable && M <= 4096 && M >= 2;
+        for (int k = 0; k < M && t.closed_form; ++k) {
+            const long long q = ((long long)k * (N - 1)) / (M - 1);
+            const int want = (int)(q < N - 2 ? q : N - 2);
+            if (orow[k] != want || ocol[k] != want) t.closed_form = false;
+        }
         // four consecutive fine columns starting on a multiple of 4 span at most three coarse cells: what the
         // 4-columns-per-lane form of the fused prolongation (fp32 fields) holds per lane
         t.fusable4 = fusable && M % 4 == 0;

@@ -32,6 +32,7 @@ void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in,
         tb.p_clo = pt->col_lo;
         tb.c_dx = pt->c_dx;
         tb.c_dx_rcp = 1.0 / pt->c_dx;  // IEEE division on the host: correctly rounded
+        tb.p_closed = pt->closed_form;
     }
     if (Fc) {
         tb.r_inv = rt->inv;

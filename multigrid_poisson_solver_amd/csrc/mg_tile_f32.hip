@@ -22,6 +22,7 @@ void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in
         tb.p_clo = pt->col_lo_f;
         tb.c_dx = (float)pt->c_dx;
         tb.c_dx_rcp = 1.0f / tb.c_dx;  // IEEE fp32 division on the host: correctly rounded
+        tb.p_closed = pt->closed_form;
     }
     if (Fc) {
         tb.r_inv = rt->inv;

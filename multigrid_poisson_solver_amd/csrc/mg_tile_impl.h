@@ -57,6 +57,7 @@ struct TileParams {
     int no_out;         // the smoothed U is not stored
     int d_sign;
     double *part;       // nullptr: no error norm; else one partial per wave
+    long long *trace;   // MG_TILE_TRACE builds only
     int tiles_x, n_blocks;
     // T_PROLONG: coarse grid and the host-built tables of doProlongation
     const real_t *coarse;
@@ -64,6 +65,8 @@ struct TileParams {
     const int *p_orow, *p_ocol;
     const real_t *p_rhi, *p_rlo, *p_chi, *p_clo;
     real_t c_dx, c_dx_rcp;
+    int own_closed;     // ProlongTable::closed_form: owner(k) = min(k*(Nc-1)/(N-1), Nc-2), formed in the kernel
+    float own_rcp;      // 1/(N-1), for that division
     // RESTRICT: next level's F and the host-built tables of doRestriction
     real_t *Fc;
     int M;
@@ -96,6 +99,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
 
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of tiles (a band of rows),
     // so the halo re-reads of neighbouring tiles hit its L2.  Speed only, never correctness.
+#ifdef MG_TILE_TRACE   // diagnostics: where a launch spends its time (100 MHz timestamps of the middle tile's wave 0)
+    const long long tr0 = wall_clock64();
+#define TILE_STAMP(k) do { if (p.trace && tile_id == p.n_blocks / 2 && threadIdx.x == 0) p.trace[k] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(k) do { } while (0)
+#endif
     const int per_xcd = (p.n_blocks + 7) >> 3;
     const int tile_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile_id >= p.n_blocks) return;   // (the whole workgroup: no barrier is left waiting)
@@ -124,6 +133,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     auto row_owned = [&](int j) { return (unsigned)(yb + j - oy0) < (unsigned)(oy1 - oy0); };
 
     // ---- every load of the node, issued in one batch ---------------------------------------------------------------
+    // wave-uniform per-row table entries ride in one register per table, row j of the block in lane j (v_readlane)
+    const int yl = yb + (lane < RPW ? lane : RPW - 1);
+    const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);
+    // The owner cells of the fused prolongation are ADDRESS ingredients of the coarse loads: read from their tables they
+    // put a whole memory round trip in front of those loads (measured: 1.2-4 us from kernel start to the last load
+    // issued, of a ~5 us kernel).  For the level pairs of a halving hierarchy the owner is min(k*(Nc-1)/(N-1), Nc-2) in
+    // integer arithmetic -- the host checked that against the reference's ceil() tables entry by entry
+    // (ProlongTable::closed_form) -- so the kernel forms it itself; other pairs read the tables, first of all loads.
+    int t_own = 0, cj = 0;
+    if constexpr (IN == T_PROLONG) {
+        if (p.own_closed) {
+            auto owner_of = [&](int k) {   // k*(Nc-1) < 2^23: exact in fp32; the quotient estimate is off by at most one
+                const int n = k * (p.Nc - 1), d = N - 1;
+                int q = (int)((float)n * p.own_rcp);
+                const int r = n - q * d;
+                q += (r >= d) ? 1 : 0;
+                q -= (r < 0) ? 1 : 0;
+                return q < p.Nc - 2 ? q : p.Nc - 2;
+            };
+            t_own = owner_of(ylc);
+            cj = owner_of(xc);
+        } else {
+            t_own = p.p_orow[ylc];
+            cj = p.p_ocol[xc];
+        }
+    }
     real_t f[RPW], v[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) f[j] = p.F[(size_t)row_clamped(j) * N + xc];
@@ -131,18 +166,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
 #pragma unroll
         for (int j = 0; j < RPW; ++j) v[j] = p.in[(size_t)row_clamped(j) * N + xc];
     }
-    // wave-uniform per-row table entries ride in one register per table, row j of the block in lane j (v_readlane)
-    const int yl = yb + (lane < RPW ? lane : RPW - 1);
-    const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);
-    int t_own = 0;
     real_t t_rhi = 0, t_rlo = 0, pc_hi = 0, pc_lo = 0;
     real_t ca[RPW], cb[RPW], c0a = 0, c0b = 0;
     int own[RPW];
     if constexpr (IN == T_PROLONG) {
-        t_own = p.p_orow[ylc];
         t_rhi = p.p_rhi[ylc];
         t_rlo = p.p_rlo[ylc];
-        const int cj = p.p_ocol[xc];
         pc_hi = p.p_chi[xc];
         pc_lo = p.p_clo[xc];
         const int last = p.Nc - 1;
@@ -170,13 +199,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
         t_rc = ok ? rc : -1;
         if (lane_owns) {
             rc_col = p.r_inv[x];
-            if (rc_col >= 0) {
-                rw_a = p.r_w[rc_col];
-                rw_b = real_t(1.0) - rw_a;  // src/MG_solver_CPU.cpp:665
-            }
+            rw_a = p.r_wf[x];           // = r_w[rc_col], by fine index: no load behind a load
+            rw_b = real_t(1.0) - rw_a;  // src/MG_solver_CPU.cpp:665
         }
     }
 
+#ifdef MG_TILE_TRACE
+    if (p.trace && tile_id == p.n_blocks / 2 && threadIdx.x == 0) p.trace[0] = tr0;
+    TILE_STAMP(1);                                  // loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TILE_STAMP(2);                                  // loads back
+#endif
     // ---- level 0 -------------------------------------------------------------------------------------------------
     if constexpr (IN == T_PROLONG) {
         // U + P(coarse): doProlongation :700 as a gather, then doGridAddition :569 -- the streaming kernel's expressions:
@@ -239,6 +272,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
         for (int j = 0; j < RPW; ++j) v[j] = o[j];
     }
 
+    TILE_STAMP(3);                                  // sweeps done
     // ---- the smoothed U ---------------------------------------------------------------------------------------------
     if (!p.no_out && lane_owns) {
 #pragma unroll
@@ -269,16 +303,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
             acc += fabs(bits_and((double)r, am));
         }
         if (p.part) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-            if (lane == 0) p.part[(size_t)tile_id * WAVES + wave] = acc;
+            const double total = wave_sum_dpp(acc);
+            if (lane == 0) p.part[(size_t)tile_id * WAVES + wave] = total;
         }
         if constexpr (RESTRICT) {
             // the row after the block's last one: the next wave's first
             real_t d_next, unused;
             exchange(d[0], d[RPW - 1], unused, d_next);
             (void)unused;
-            const bool first_col_lane = lane_owns && x == 0, last_col_lane = lane_owns && x == N - 1;
+            // (wave-uniform tile conditions first: interior tiles skip the rim stores without touching the exec mask)
+            const bool first_col_lane = tile_x == 0 && lane_owns && x == 0, last_col_lane = ox1 == N && lane_owns && x == N - 1;
             // the rim of the next level's F is zero (doRestriction's memset, :651): rim rows by the tiles that hold fine
             // rows 0 and N-1, rim columns by the lanes that own fine columns 0 and N-1 alongside every coarse row
             if (wave == 0) {
@@ -301,11 +335,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
                 const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
                 real_t *crow = p.Fc + (size_t)rc_row * p.M;
                 if (rc_col >= 0) crow[rc_col] = vc;
-                if (first_col_lane) crow[0] = 0.0;
-                if (last_col_lane) crow[p.M - 1] = 0.0;
+                if (tile_x == 0 && first_col_lane) crow[0] = 0.0;
+                if (ox1 == N && last_col_lane) crow[p.M - 1] = 0.0;
             }
         }
     }
+    TILE_STAMP(4);                                  // residual / restriction issued
+#ifdef MG_TILE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TILE_STAMP(5);                                  // stores acknowledged
+#endif
 }
 
 // geometry of one instantiation, for the launcher
@@ -324,7 +363,23 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out)
         if (!p.part) return;
     }
     const int grid = ((p.n_blocks + 7) / 8) * 8;
+#ifdef MG_TILE_TRACE
+    static long long *trace_dev = nullptr;
+    if (!trace_dev) (void)hipMalloc((void **)&trace_dev, 8 * sizeof(long long));
+    (void)hipMemsetAsync(trace_dev, 0, 8 * sizeof(long long), s);
+    p.trace = trace_dev;
+#endif
     hipLaunchKernelGGL((k_jacobi_tile<S, IN, RESTRICT, RPW, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p);
+#ifdef MG_TILE_TRACE
+    {
+        long long t[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(t, trace_dev, sizeof t, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[tile trace] N=%d S=%d IN=%d R=%d rpw=%d tiles=%d: to loads issued %.2f, loads back %.2f, sweeps %.2f, residual+restrict %.2f, stores %.2f us\n",
+                N, S, IN, (int)RESTRICT, RPW, p.n_blocks, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01,
+                (t[5] - t[4]) * 0.01);
+    }
+#endif
     if (err_out) norm_finish(s, p.part, n_part, N, err_out);
 }
 
@@ -335,7 +390,7 @@ void launch_geom(hipStream_t s, const TileParams &p, double *err_out)
 {
     static const int forced = [] { const char *e = getenv("MG_TILE_RPW"); return e ? atoi(e) : 0; }();
     constexpr int HALO = Geom<S, IN, RESTRICT>::HALO;
-    const int rpw = forced ? forced : (p.N <= 256 ? 6 : 12);
+    const int rpw = forced ? forced : (p.N <= 512 ? 6 : 12);   // (measured, V(3,3): N = 512 8.2 + 7.8 us with 6 rows per wave, 9.1 + 8.5 with 12; N = 1024 equal)
     if (rpw <= 6 && 4 * 6 - 2 * HALO >= 8) launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out);
     else launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out);
 }
@@ -359,6 +414,7 @@ struct Tables {
     const int *p_orow = nullptr, *p_ocol = nullptr;
     const real_t *p_rhi = nullptr, *p_rlo = nullptr, *p_chi = nullptr, *p_clo = nullptr;
     real_t c_dx = 0, c_dx_rcp = 0;
+    bool p_closed = false;   // ProlongTable::closed_form
     const int *r_inv = nullptr;
     const real_t *r_w = nullptr, *r_wf = nullptr;
 };
@@ -398,6 +454,9 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         p.p_clo = tb.p_clo;
         p.c_dx = tb.c_dx;
         p.c_dx_rcp = tb.c_dx_rcp;
+        static const bool no_closed = getenv("MG_TILE_NO_CLOSED_FORM") != nullptr;   // A/B switch
+        p.own_closed = (tb.p_closed && !no_closed && N <= 4096) ? 1 : 0;
+        p.own_rcp = 1.0f / (float)(N - 1);
     }
     if (Fc) {
         p.Fc = Fc;

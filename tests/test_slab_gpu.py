@@ -74,18 +74,27 @@ def test_virtual_slabs_on_the_weak_scaling_size_family(mg, oracle, tmp_path, R, 
     single.close()
 
 
-@pytest.mark.parametrize("N,mixed", [(4096, False), (8192, False), (8192, True), (16384, False), (32768, True)])
-def test_virtual_slabs_match_single_gpu_driver_at_full_size(mg, tmp_path, N, mixed):
+@pytest.mark.parametrize("N,mixed,refine", [(4096, False, 1), (8192, False, 1), (8192, True, 1), (16384, False, 1), (32768, True, 1),
+                                            (32768, True, 2)])
+def test_virtual_slabs_match_single_gpu_driver_at_full_size(mg, tmp_path, N, mixed, refine):
     """8 slabs of a V-cycle (fp64 and fp32 fields) against the single-GPU driver (itself pinned to the
     oracle up to 8192^2, tests/test_cycle_gpu.py).  16384^2 fp64 and 32768^2 mixed are the sizes of
-    BASELINE.json configs[3] and configs[4]; there the results are compared through the checksum."""
+    BASELINE.json configs[3] and configs[4]; there the results are compared through the checksum.
+    (32768, mixed, refine = 2) is configs[4] AS WRITTEN -- "mixed fp32 smoothing / fp64 residual correction": two fp32
+    cycles joined by the fp64 residual of the fp64 iterate and an fp64 correction, on 8 slabs and on one GPU: the fp64
+    iterate (checksum), every smoothing error and the residual norm of the refinement must agree."""
     path = str(tmp_path / f"V{N}.txt")
     mg.write_vcycle_file(path, N, 8, 3, 1e-7)
-    single = mg.CyclePlan(path, fused=True, report=False, mixed=mixed)
+    single = mg.CyclePlan(path, fused=True, report=False, mixed=mixed, refinement=refine)
     big = N > 8192
     ref = single.execute(fetch_U=not big)
-    plan = mg.SlabPlan(path, 8, -1, 1024 if N >= 8192 else 512, mixed=mixed)
+    plan = mg.SlabPlan(path, 8, -1, 1024 if N >= 8192 else 512, mixed=mixed, refinement=refine)
     got = plan.execute()
+    assert got["status"] == 0 and ref["status"] == 0
+    if refine > 1:
+        assert len(got["refinement_errors"]) == refine - 1 and len(ref["refinement_errors"]) == refine - 1
+        for g, w in zip(got["refinement_errors"], ref["refinement_errors"]):
+            assert g == pytest.approx(w, rel=1e-12) and g > 0
     if big:
         import ctypes as C
         import _synth
