@@ -77,8 +77,15 @@ void Pool::put(void *p)
         fail(MG_ERR_ARG, "mg_free: pointer %p was not returned by mg_alloc", p);
         return;
     }
-    free_.emplace(it->second, p);
+    if (park_) parked_.emplace_back(it->second, p);
+    else free_.emplace(it->second, p);
     live_.erase(it);
+}
+
+void Pool::release_parked()
+{
+    for (auto &kv : parked_) free_.emplace(kv.first, kv.second);
+    parked_.clear();
 }
 
 void Pool::trim()
@@ -151,6 +158,7 @@ double *norm_partials(size_t n)
 {
     Context &c = ctx();
     if (!c.defer_norms) return partials(n);
+    c.norm_window_total += n;
     if (c.norm_arena_used + n > c.norm_arena_cap) {
         // grow; what is pending keeps pointing into the old arena, which stays alive
         size_t cap = c.norm_arena_cap ? c.norm_arena_cap * 2 : (size_t)1 << 16;
@@ -174,7 +182,7 @@ void norm_finish(hipStream_t s, const double *part, size_t n, int N, double *out
         return;
     }
     c.pending_norms.push_back(Context::PendingNorm{part, (int)n, N, out});
-    if ((int)c.pending_norms.size() >= k::MAX_NORMS_PER_FLUSH) flush_norms();
+    if ((int)c.pending_norms.size() >= k::MAX_NORMS_PER_FLUSH && !c.norms_at_window_end) flush_norms();
 }
 
 void flush_norms()
@@ -188,11 +196,30 @@ void flush_norms()
         b.out[count] = pn.out;
         b.n[count] = pn.n;
         b.N[count] = pn.N;
-        ++count;
+        if (++count == k::MAX_NORMS_PER_FLUSH) {   // (only a window that held its norms back to the end has more than one batch)
+            k::finish_smoothing_errors(c.stream, b, count);
+            count = 0;
+        }
     }
-    k::finish_smoothing_errors(c.stream, b, count);
+    if (count) k::finish_smoothing_errors(c.stream, b, count);
     c.pending_norms.clear();
     c.norm_arena_used = 0;  // stream order: later partials are written after this reduction ran
+    // An arena that grew in mid-window holds only what came after its last growth: size it for ALL partials between two
+    // flushes now, so that the same window run again -- possibly under stream capture, where hipMalloc is not allowed --
+    // finds room.  (The old arena stays alive: the reduction just enqueued reads it.)
+    if (c.norm_window_total > c.norm_arena_cap && !stream_is_capturing(c.stream)) {
+        size_t cap = c.norm_arena_cap ? c.norm_arena_cap : (size_t)1 << 16;
+        while (cap < c.norm_window_total) cap *= 2;
+        double *bigger = nullptr;
+        if (hipMalloc((void **)&bigger, cap * sizeof(double)) == hipSuccess) {
+            if (c.norm_arena) c.retired.push_back(c.norm_arena);
+            c.norm_arena = bigger;
+            c.norm_arena_cap = cap;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    c.norm_window_total = 0;
 }
 
 namespace {

@@ -35,6 +35,11 @@ struct LevelNode {  // src/linkedlist.h:4-30
     // > 0: U holds nothing yet -- it is `pending_pre` Jacobi sweeps from zero on this F, which the fused `-1` node did
     // not store (smooth_restrict_no_out); the fused `1` node recomputes it in flight, anyone else calls ensure_U first
     int pending_pre = 0;
+    // independent sub-cycles (mg_cycle_plan::fork): how many `-1` nodes have left this level since it was pushed, and the
+    // event after which its F is complete (recorded behind the restriction that produced it)
+    int descents = 0;
+    hipEvent_t f_ready = nullptr;
+    hipStream_t f_stream = nullptr;  // where f_ready was recorded (a wait on the same stream is implied by stream order)
 };
 
 class LevelList {
@@ -155,6 +160,22 @@ struct mg_cycle_plan {
     int warm_runs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_status = 0;
+    // ---- independent sub-cycles on their own streams ----------------------------------------------------------------
+    // The reference zeroes a level's U before every pre-smoothing except the restart case (src/MG_solver_CPU.cpp:252-257),
+    // so a `-1` node reads nothing but its level's F.  When a cycle file comes back up to a level and descends from it
+    // AGAIN (the second half of every W-cycle visit: ... 1 -1 ...), that second sub-cycle depends on the level's F alone
+    // -- not on anything the first sub-cycle produced (whose result the zero fill discards; only its smoothing errors
+    // are ever looked at).  The driver therefore starts it on another stream, behind the event of that F, and lets the
+    // first sub-cycle finish on the stream it was enqueued on.  Every node still runs, with the same inputs, the same
+    // launches and the same bits; records and report are assembled in file order as always.  What changes is that
+    // kernels of a few workgroups each (one workgroup for a coarse-tail launch) no longer queue behind one another.
+    bool fork = false;               // the file has such re-descents above the coarse tail and every node in it is fork-safe
+    int fork_max_N = 0;              // re-descents from levels up to this size fork (larger levels fill the GPU on their own)
+    std::vector<hipStream_t> side;   // stream pool of the forked sub-cycles (round robin)
+    std::vector<hipEvent_t> events;  // F-ready and join events, reused window after window
+    size_t events_used = 0;
+    int *gs_slots = nullptr;         // [2 * launches] exact-solver state per coarse-tail launch (concurrent launches must not share one)
+    int tail_launches = 0;
 };
 
 namespace mg {
@@ -285,6 +306,10 @@ struct Exec {
     int status = 0;
     bool capturing = false;
     bool widened = false;  // mixed mode: the last node stored its result in fp64 (plan->U64) itself
+    bool forking = false;  // this pass starts re-descents on side streams (plan->fork)
+    hipStream_t home = nullptr;      // the engine's stream: where the window starts and, after the join, ends
+    std::vector<char> side_used;
+    size_t next_side = 0;
 
     bool next(double *v)
     {
@@ -353,6 +378,66 @@ void ensure_U(mg_cycle_plan *p, LevelNode *lv)
     if (p->flags & MG_CYCLE_MIXED) return;  // fp32 fields: every consumer is a fused `1` node (run_nodes turns anything else into status 15)
     mg_smooth_pp(lv->N, p->L, nullptr, lv->U, lv->F, lv->pending_pre, nullptr, nullptr, -1);
     lv->pending_pre = 0;
+}
+
+hipEvent_t next_event(mg_cycle_plan *p)
+{
+    if (p->events_used == p->events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        p->events.push_back(e);
+    }
+    return p->events[p->events_used++];
+}
+
+// A re-descent from lv (zero start: it reads lv->F and nothing else) begins on the next side stream, behind the event of
+// that F.  The sub-cycle enqueued before it may still be running: it keeps the level's old U and D (they return to the pool
+// when the window ends: Pool::park), this one gets fresh ones.  Everything that follows in the file -- this sub-cycle and
+// the way up from it -- stays on the new stream; the old stream only has to finish what it holds before the window ends.
+void fork_branch(Exec &x, LevelNode *lv)
+{
+    mg_cycle_plan *p = x.p;
+    const size_t k = x.next_side++ % p->side.size();
+    hipStream_t t = p->side[k];
+    if (lv->f_stream != t) (void)hipStreamWaitEvent(t, lv->f_ready, 0);
+    x.c.stream = t;
+    x.side_used[k] = 1;
+    const size_t bytes = (size_t)lv->N * lv->N * sizeof(double);
+    p->pool.put(lv->U);
+    p->pool.put(lv->D);
+    lv->U = (double *)p->pool.get(bytes);
+    lv->D = (double *)p->pool.get(bytes);
+    lv->pending_pre = 0;
+}
+
+// the window ends on the engine's stream, behind everything any side stream still holds
+void join_branches(Exec &x)
+{
+    if (!x.forking) return;
+    mg_cycle_plan *p = x.p;
+    hipStream_t cur = x.c.stream;
+    for (size_t k = 0; k < p->side.size(); ++k) {
+        if (!x.side_used[k] || p->side[k] == cur) continue;
+        hipEvent_t e = next_event(p);
+        if (!e) { x.status = 16; continue; }
+        (void)hipEventRecord(e, p->side[k]);
+        (void)hipStreamWaitEvent(cur, e, 0);
+    }
+    if (cur != x.home) {
+        hipEvent_t e = next_event(p);
+        if (!e) x.status = 16;
+        else {
+            (void)hipEventRecord(e, cur);
+            (void)hipStreamWaitEvent(x.home, e, 0);
+        }
+    }
+    x.c.stream = x.home;
+    // mg_lastExactSolverIterations(): the state of the LAST coarse-tail launch of the file (each launch had its own slot)
+    if (p->tail_launches > 0)
+        (void)hipMemcpyAsync(x.c.gs_state, p->gs_slots + 2 * (p->tail_launches - 1), 2 * sizeof(int), hipMemcpyDeviceToDevice, x.home);
 }
 
 // fixed-step smoothing of the last level, result in lv->U.  zero_start: the driver's
@@ -450,7 +535,7 @@ bool try_tail(Exec &x)
     a.F_top = top->F;
     a.U_top = top->U;
     a.err_dev = p->err_dev;
-    a.gs_state = x.c.gs_state;
+    a.gs_state = x.forking ? p->gs_slots + 2 * p->tail_launches++ : x.c.gs_state;
     // diagnostics: MG_TAIL_TRACE=1 prints the in-kernel timeline of the first traced launches
     static const bool trace_on = getenv("MG_TAIL_TRACE") != nullptr;
     static int traced = 0;
@@ -497,6 +582,15 @@ void run_nodes(Exec &x)
     const bool fused = (p->flags & MG_CYCLE_FUSED) != 0;
     const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0;
     x.c.defer_norms = true;
+    x.forking = p->fork && fused && !mixed;
+    x.home = x.c.stream;
+    if (x.forking) {
+        x.side_used.assign(p->side.size(), 0);
+        p->events_used = 0;
+        p->tail_launches = 0;
+        x.c.norms_at_window_end = true;   // a mid-window reduction could run ahead of nodes on other streams
+        p->pool.park(true);               // no block changes hands between streams inside the window
+    }
 
     for (;;) {
         int node;
@@ -557,10 +651,13 @@ void run_nodes(Exec &x)
             } else if (fused) {
                 // smoothing (:259), residual (:268), sign flip (:277-280) and restriction (:287)
                 // in one pass; the zero fill of U (:256) is folded into the first sweep
+                // a second descent from this level reads its F alone: on its own stream (see mg_cycle_plan::fork)
+                if (x.forking && !keep && lv->descents > 0 && lv->f_ready && lv->N <= p->fork_max_N) fork_branch(x, lv);
+                lv->descents++;
                 rec = add_record(p, -1, lv->N, step);
                 report_smoothing(p, rec);
                 cycle.Push_back(next_N);  // :283
-                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D) { x.status = 14; break; }  // out of device memory
+                if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D || !lv->U || !lv->D) { x.status = 14; break; }  // out of device memory
                 double *Fc = cycle.last()->F;
                 lv->pending_pre = 0;
                 if (!keep && p->con_step > 0 && recompute_available(next_N, lv->N, step, p->con_step)) {
@@ -577,6 +674,14 @@ void run_nodes(Exec &x)
                     p->pool.put(tmp);
                 }
                 report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
+                if (x.forking && next_N > k::TAIL_MAX_N && next_N <= p->fork_max_N) {
+                    // the new level's F is complete behind this launch: what a later re-descent from it waits for
+                    hipEvent_t e = next_event(p);
+                    if (e && hipEventRecord(e, x.c.stream) == hipSuccess) {
+                        cycle.last()->f_ready = e;
+                        cycle.last()->f_stream = x.c.stream;
+                    }
+                }
                 try_tail(x);  // levels N <= 64: the rest of this descent and its way back up in one launch
                 continue;
             } else {
@@ -711,8 +816,13 @@ void run_nodes(Exec &x)
         if (mixed) x.status = 15;
         else ensure_U(p, cycle.last());
     }
+    join_branches(x);
     flush_norms();  // the window's smoothing errors: one reduction launch
     x.c.defer_norms = false;
+    if (x.forking) {
+        x.c.norms_at_window_end = false;
+        p->pool.park(false);
+    }
 }
 
 // reset the level stack to the state right after getSource (:149-153)
@@ -722,8 +832,62 @@ void reset_levels(mg_cycle_plan *p)
     // keep the finest level (its F never changes); drop anything a broken file left over
     while (cycle.depth() > 1) cycle.Remove_back();
     cycle.Set_init(1);
+    if (cycle.first()) {
+        cycle.first()->descents = 0;
+        cycle.first()->f_ready = nullptr;
+    }
+    // blocks the previous window set aside: its streams were joined on the engine's stream, which everything of this
+    // window is ordered behind
+    p->pool.release_parked();
     p->records.clear();
     p->report_items.clear();
+}
+
+// Does the file descend again from a level it has come back up to (mg_cycle_plan::fork), above the coarse tail and at most
+// max_n wide, and is every node fork-safe (exact solves only inside coarse-tail launches, which get a state slot each)?
+void plan_forks(mg_cycle_plan *p)
+{
+    static const bool on = [] { const char *e = getenv("MG_CYCLE_FORK"); return !e || atoi(e) != 0; }();
+    static const int max_n = [] { const char *e = getenv("MG_FORK_MAX_N"); return e ? atoi(e) : 4096; }();
+    // (measured, W(3,3) at 8192, default 4 hardware queues: 8 / 16 / 32 streams 4.84 / 4.30 / 4.12 ms with forks up to level 4096,
+    // 5.23 / 4.56 / 4.34 with forks up to 1024; serial 10.13; GPU_MAX_HW_QUEUES=8 or 16 is SLOWER: 6.3-8.1 ms)
+    static const int n_streams = [] { const char *e = getenv("MG_FORK_STREAMS"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    if (!on || getenv("MG_NO_TAIL")) return;
+    std::vector<int> descents(1, 0);
+    size_t at = 0, tok = 0;
+    bool points = false;
+    while (tok < p->tokens.size()) {
+        const int node = (int)p->tokens[tok++];
+        if (node == 2) break;
+        if (node == -1) {
+            if (at + 1 >= p->sizes.size()) break;  // (the run ends with status 4)
+            const int N = p->sizes[at];
+            if (descents.back() > 0 && N > k::TAIL_MAX_N && N <= max_n) points = true;
+            descents.back()++;
+            descents.push_back(0);
+            ++at;
+        } else if (node == 0) {
+            tok += 2;
+            if (p->sizes[at] > k::TAIL_MAX_N) return;  // a stand-alone exact solve: shared solver state
+        } else if (node == 1) {
+            if (descents.size() < 2) break;
+            descents.pop_back();
+            --at;
+        }
+    }
+    if (!points) return;
+    p->gs_slots = (int *)p->pool.get(2 * p->err_cap * sizeof(int));
+    if (!p->gs_slots) return;
+    for (int i = 0; i < n_streams; ++i) {
+        hipStream_t t = nullptr;
+        if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        p->side.push_back(t);
+    }
+    p->fork = !p->side.empty();
+    p->fork_max_N = max_n;
 }
 
 bool uses_trigger(const mg_cycle_plan *p)
@@ -786,6 +950,7 @@ mg_cycle_plan *mg_cycle_load(const char *path, int flags)
         delete p;
         return nullptr;
     }
+    if ((flags & MG_CYCLE_FUSED) && !mixed && p->con_N == 1 && p->con_step >= 1 && p->err_dev) plan_forks(p);
     p->levels = new LevelList(&p->pool, mixed ? sizeof(float) : sizeof(double));
     p->levels->Push_back(p->N_max);  // :149
     LevelNode *top = p->levels->last();
@@ -823,8 +988,11 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     if (!require_ready("mg_cycle_enqueue") || !p) return 1;
     Context &c = ctx();
     hipStream_t s = c.stream;
+    // (a plan that forks its independent sub-cycles onto side streams is not captured: hipStreamEndCapture of that
+    // multi-stream capture crashed inside the ROCm 7.2 runtime for W-cycles from N = 4096 on -- it worked up to 2048 --
+    // and the eager forked window is 2.4 times faster than the replayed serial one anyway: 4.1 against 10.1 ms at 8192)
     const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
-                            !uses_trigger(p) && !p->graph_failed;
+                            !uses_trigger(p) && !p->graph_failed && !p->fork;
     int status = 0;
     (void)hipEventRecord(p->ev0, s);
 
@@ -856,15 +1024,21 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) x.capturing = true;
             else { (void)hipGetLastError(); p->graph_failed = true; }
         }
+        static const bool dbg = getenv("MG_CYCLE_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[cycle] run_nodes: capturing=%d fork=%d\n", (int)x.capturing, (int)p->fork);
         run_nodes(x);
         status = x.status;
+        if (dbg) fprintf(stderr, "[cycle] run_nodes done: status %d, events %zu, tail launches %d\n", status, p->events_used, p->tail_launches);
         if (x.capturing) {
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(s, &g);
+            if (dbg) fprintf(stderr, "[cycle] end capture: %s\n", hipGetErrorString(e));
             if (e == hipSuccess && status == 0 && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                if (dbg) fprintf(stderr, "[cycle] instantiated\n");
                 p->graph = g;
                 p->graph_ready = true;
                 if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+                if (dbg) fprintf(stderr, "[cycle] launched: status %d\n", status);
             } else {
                 (void)hipGetLastError();
                 if (g) (void)hipGraphDestroy(g);
@@ -1009,6 +1183,14 @@ void mg_cycle_destroy(mg_cycle_plan *p)
         p->levels->clear();
         delete p->levels;
     }
+    for (hipStream_t t : p->side) {
+        (void)hipStreamSynchronize(t);
+        (void)hipStreamDestroy(t);
+    }
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->pool.park(false);
+    p->pool.release_parked();
+    if (p->gs_slots) p->pool.put(p->gs_slots);
     if (p->err_dev) p->pool.put(p->err_dev);
     if (p->refine_err_dev) p->pool.put(p->refine_err_dev);
     if (p->F64) p->pool.put(p->F64);

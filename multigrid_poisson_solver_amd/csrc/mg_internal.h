@@ -77,9 +77,16 @@ public:
     void put(void *p);
     void trim();
     size_t bytes_held() const { return held_; }
+    // Reuse of a returned block normally relies on stream order (the next user enqueues behind the last one).  While
+    // a plan runs independent sub-cycles on several streams that no longer holds: with park(true) returned blocks are
+    // set aside instead of becoming available, until release_parked() -- called where all streams have been joined.
+    void park(bool on) { park_ = on; }
+    void release_parked();
 private:
     std::multimap<size_t, void *> free_;   // size -> block
     std::map<void *, size_t> live_;        // block -> size
+    std::vector<std::pair<size_t, void *>> parked_;
+    bool park_ = false;
     size_t held_ = 0;
 };
 
@@ -106,9 +113,11 @@ struct Context {
     // per-wave partial sums in an arena; ONE kernel per flush finishes all of them
     struct PendingNorm { const double *part; int n; int N; double *out; };
     bool defer_norms = false;
+    bool norms_at_window_end = false;      // never flush in mid-window (nodes may still be running on other streams)
     std::vector<PendingNorm> pending_norms;
     double *norm_arena = nullptr;
     size_t norm_arena_cap = 0, norm_arena_used = 0;
+    size_t norm_window_total = 0;          // partials requested since the last flush (sizes the arena for the next window)
     double *scalars = nullptr;            // [64] device scalars (errors, norms)
     int *gs_state = nullptr;              // [4]: done flag, iteration count, ...
     double *host_scalars = nullptr;       // pinned [64]

@@ -165,6 +165,27 @@ def test_back_to_back_windows(mg, oracle, tmp_path):
         plan.close()
 
 
+@pytest.mark.parametrize("N,steps", [(1024, 3), (512, 2)])
+def test_wcycle_forked_subcycles_back_to_back(mg, oracle, tmp_path, N, steps):
+    """W-cycles run the second descent from a level (which reads that level's F and nothing else: the reference zeroes
+    U before every pre-smoothing, src/MG_solver_CPU.cpp:252-257) on another stream, beside the sub-cycle enqueued before
+    it (mg_cycle.cpp: mg_cycle_plan::fork).  Several windows back to back -- buffers set aside by one window are reused
+    by the next, events and streams too -- eager and replayed from a graph: every window's final U, every record and
+    the last coarse solve's iteration count as the oracle's."""
+    path = str(tmp_path / "W.txt")
+    mg.write_wcycle_file(path, N, 8, steps, 1e-7)
+    want = oracle.run_cycle_file(path)
+    for graph in (False, True):
+        plan = mg.CyclePlan(path, fused=True, graph=graph)
+        for _ in range(2):
+            check_against(plan.execute(fetch_U=True), want, zero_sign=True)
+        for _ in range(4):
+            plan.enqueue()
+        check_against(plan.collect(fetch_U=True), want, zero_sign=True)
+        assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+        plan.close()
+
+
 def test_coarse_tail_matches_node_by_node(mg, tmp_path):
     """MG_NO_TAIL=1 (read once per process) cannot be toggled here, so compare the fused driver
     (tail kernel for N <= 64) with the unfused one (operator by operator) on a deep hierarchy."""
@@ -352,6 +373,13 @@ def test_product_thresholds_on_the_small_and_medium_levels(mg, oracle, tmp_path)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
     assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-3000:]
     child = json.loads(line[0][len("DEFAULTS_WORKER "):])
+    # the W-cycles once more with every sub-cycle on the one stream, in file order (MG_CYCLE_FORK=0): the same numbers
+    serial = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_defaults_worker.py")] + [sp for sp in specs if sp[0] == "W"],
+                            env=dict(env, MG_CYCLE_FORK="0"), capture_output=True, text=True, timeout=900)
+    sline = [ln for ln in serial.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
+    assert serial.returncode == 0 and sline, serial.stdout[-2000:] + serial.stderr[-3000:]
+    for sp, rec in json.loads(sline[0][len("DEFAULTS_WORKER "):]).items():
+        assert rec["sum"] == child[sp]["sum"] and rec["errors"] == child[sp]["errors"], f"{sp}: forked and serial W-cycle differ"
     for spec in specs:
         kind, N, steps = spec.split(":")
         N, steps = int(N), int(steps)
