@@ -570,8 +570,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
     // the loop body covers 8 rows, so the parity of the residual row is a compile-time property of the position in
     // the body once the parity of the chunk's first residual row is folded into the masks
     int nm_k0[COLS], nm_k1[COLS];  // masks of the residual rows at even / odd positions k
+    const bool first_odd = ((y_first - L - 1) & 1) != 0;   // parity of the first residual row (wave-uniform)
     {
-        const bool first_odd = ((y_first - L - 1) & 1) != 0;
 #pragma unroll
         for (int j = 0; j < COLS; ++j) {
             nm_k0[j] = first_odd ? nm_odd[j] : nm_even[j];
@@ -629,6 +629,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
             auto add_prolongation = [&](Row<COLS> &row) {
                 if (own_i >= 0) {
                     if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
+                        // (kept a wave-uniform BRANCH: if-converted, the rotation costs its selects and the interpolation
+                        // on every row instead of on every other one)
+                        asm volatile("" ::);
 #pragma unroll
                         for (int j = 0; j < COLS; ++j) hA[j] = hB[j];
                         c_row = own_i;
@@ -662,8 +665,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                         // `- 4*U` and `U +` of the general expression below are exact no-ops -- the same bits without them
 #pragma unroll
                         for (int j = 0; j < COLS; ++j) {
-                            const real_t t4 = real_t(0.0) - dx2 * f.v[j];
-                            o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), t4, real_t(0.0));
+                            // q*(0 - dx2*F) + 0: `0 - p` is -p exactly, and whichever zero the product is, adding +0 gives +0:
+                            // the negation rides on the fma's operand instead of costing a subtraction
+                            o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), -(dx2 * f.v[j]), real_t(0.0));
                         }
                         older[l - 1] = c;
                         newer[l - 1] = nw;
@@ -743,15 +747,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const Strea
                     if constexpr (RESTRICT) {
                         d.v[j] = r * hi_bits_and(ms[j], inner);  // sign flip :277-280 and the zero rim in one exact product
                     } else {
-                        const real_t dv = (inner != 0 && !col_edge[j]) ? r : real_t(0.0);
-                        d.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
+                        d.v[j] = r;  // (masked and signed where it is stored, below: most launches store no residual)
                     }
                     // (row+col) even interior points only, :610/:617; norms are accumulated in fp64 whatever the field type
                     const int am = ((k & 1) ? nm_k1[j] : nm_k0[j]) & cm;
                     acc += fabs(bits_and((double)r, am));
                 }
-                if (mine_row && lane_owns && p.D)
-                    store_row<COLS, false>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, d);
+                if constexpr (!RESTRICT) {
+                    if (mine_row && lane_owns && p.D) {
+                        Row<COLS> ds;
+#pragma unroll
+                        for (int j = 0; j < COLS; ++j) {
+                            const real_t dv = (inner != 0 && !col_edge[j]) ? d.v[j] : real_t(0.0);
+                            ds.v[j] = p.d_sign < 0 ? -dv : dv;  // the driver's sign flip :277-280
+                        }
+                        store_row<COLS, false>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, ds);
+                    }
+                } else {
+                    if (mine_row && lane_owns && p.D)
+                        store_row<COLS, false>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.D) + (st_off - (long long)row_bytes)), col_st, d);
+                }
 
                 if constexpr (RESTRICT) {
                     // doRestriction :656-678 on rows (y-1, y) of the signed residual: coarse row
