@@ -241,7 +241,9 @@ def time_cycle(mg, plan, steps, warmup, profile_min_N=None):
     r0 = plan.collect()
     assert r0["status"] == 0, r0
     if profile_min_N is not None:
-        mg.profile_begin(min_N=profile_min_N)
+        # live hipEvent pairs around the finest-level launches of every 5th timed window (a pair costs its launch
+        # ~2.5 us: 10 us on a 0.74 ms window with both fine-level launches bracketed in every window)
+        mg.profile_begin(min_N=profile_min_N, every=5 if steps >= 10 else 1)
     t0 = time.perf_counter()
     for _ in range(steps):
         plan.enqueue()

@@ -177,6 +177,8 @@ typedef struct mg_profile_entry {
     double algo_bytes;      /* ALGORITHMIC bytes of ONE launch */
 } mg_profile_entry;
 void mg_profile_begin(int min_N);
+/* time the launches of every `every`-th cycle window (mg_cycle_enqueue) only -- the 1st, the (every+1)-th, ...; 1 = all */
+void mg_profile_sample(int every);
 /* synchronises, fills out[0..cap) with one entry per (name, N), returns the count */
 int  mg_profile_end(mg_profile_entry *out, int cap);
 

@@ -91,7 +91,7 @@ ABI = {
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_gather_U": (_i, [_vp, _vp]), "mg_slab_want_error": (None, [_vp, _i]), "mg_slab_destroy": (None, [_vp]),
-    "mg_profile_begin": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
+    "mg_profile_begin": (None, [_i]), "mg_profile_sample": (None, [_i]), "mg_profile_end": (_i, [C.POINTER(ProfileEntry), _i]),
 }
 
 _lib = None
@@ -466,7 +466,8 @@ def prolongation_table(N, M, axis):
     return owner, hi, lo
 
 
-def profile_begin(min_N=0):
+def profile_begin(min_N=0, every=1):
+    lib().mg_profile_sample(int(every))
     lib().mg_profile_begin(int(min_N))
     _check()
 

@@ -132,6 +132,7 @@ ProfScope::ProfScope(const char *name, int N, double algo_bytes, hipStream_t str
     Context &c = ctx();
     on = stream ? stream : c.stream;
     if (!c.profiling || N < c.profile_min_N || stream_is_capturing(on)) return;
+    if (c.profile_every > 1 && c.profile_window % c.profile_every != 1 % c.profile_every) return;  // (windows count from 1)
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
         if (!c.event_pool.empty()) {
@@ -1192,8 +1193,13 @@ void mg_profile_begin(int min_N)
     }
     c.prof.clear();
     c.profile_min_N = min_N;
+    c.profile_window = 0;
     c.profiling = true;
 }
+
+// time the launches of every `every`-th cycle window only (the first, the (every+1)-th, ...): an event pair costs its
+// launch a few microseconds, which a benchmark does not want on every one of its timed windows.  1 = every window.
+void mg_profile_sample(int every) { ctx().profile_every = every < 1 ? 1 : every; }
 
 int mg_profile_end(mg_profile_entry *out, int cap)
 {

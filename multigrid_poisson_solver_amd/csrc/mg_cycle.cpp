@@ -994,6 +994,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
                             !uses_trigger(p) && !p->graph_failed && !p->fork;
     int status = 0;
+    c.profile_window++;
     (void)hipEventRecord(p->ev0, s);
 
     if (want_graph && p->graph_ready) {

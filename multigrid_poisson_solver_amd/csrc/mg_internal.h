@@ -130,6 +130,8 @@ struct Context {
     // profiling (mg_profile_begin/end)
     bool profiling = false;
     int profile_min_N = 0;
+    int profile_every = 1;                 // mg_profile_sample: time the launches of every k-th cycle window only
+    long profile_window = 0;               // windows enqueued since mg_profile_begin
     struct ProfRec { std::string name; int N; double bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;

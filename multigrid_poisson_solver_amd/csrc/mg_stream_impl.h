@@ -269,8 +269,19 @@ __device__ __forceinline__ void unrolled_while(F &&f, std::integer_sequence<int,
     (void)(f(std::integral_constant<int, K>{}) && ...);
 }
 
+// waves per SIMD the register allocator is asked to make room for (experiment switch MG_WPE_DOWN: the fused `-1` node
+// of fp64 fields needs 131-135 VGPRs -- three waves per SIMD, four from 128 down)
+#ifndef MG_WPE_DOWN
+#define MG_WPE_DOWN 0
+#endif
+template <int S, int COLS, int IN, bool RESTRICT, int PRE>
+struct WavesPerSimd {
+    static constexpr int min = (MG_WPE_DOWN > 0 && sizeof(real_t) == 8 && COLS == 2 && IN == 1 /* IN_ZERO */ && RESTRICT && S <= 3) ? MG_WPE_DOWN : 1;
+};
+
 template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false, int PRE = 0>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_jacobi_stream(const StreamParams p)
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(WavesPerSimd<S, COLS, IN, RESTRICT, PRE>::min)))
+void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || COLS == 4 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
     static_assert(COLS != 4 || sizeof(real_t) == 4, "4 columns per lane = one 16-byte access: fp32 fields only");

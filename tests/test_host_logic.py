@@ -152,13 +152,35 @@ def test_weak_scaling_grid_sizes():
         assert sizes[-1] >= 8 and sizes[-1] ** 2 <= 256   # the one-wave coarse solvers cover it
 
 
+def test_recompute_pair_and_closed_form_owner_predicates(m):
+    """Host-side predicates the kernels rely on (no device needed): the recomputing node pair exists for 1+1, 2+2 and 3+3
+    sweeps in the default build (mg_recompute_pair_available); and the closed form the register-tile kernel uses for the
+    owner cell of the fused prolongation, min(k*(Nc-1)/(N-1), Nc-2), reproduces the tables built from the reference's
+    ceil() expressions for the level pairs of halving hierarchies (ProlongTable::closed_form verifies this entry by
+    entry at run time; here the same comparison on the host for a spread of sizes, incl. an odd fine size where the
+    kernel would read the tables)."""
+    lib = m.load_library()
+    assert [lib.mg_recompute_pair_available(s, s) for s in (1, 2, 3, 4)] == [1, 1, 1, 0]
+    assert lib.mg_recompute_pair_available(3, 2) == 0 and lib.mg_recompute_pair_available(0, 3) == 0
+    for Nc, N in [(64, 128), (128, 256), (512, 1024), (1024, 2048), (362, 724), (45, 90), (352, 704), (90, 181), (33, 64), (2048, 4096)]:
+        k = np.arange(N, dtype=np.int64)
+        want = np.minimum(k * (Nc - 1) // (N - 1), Nc - 2)
+        for axis in (0, 1):
+            o = np.empty(N, dtype=np.int32)
+            a, b = np.empty(N), np.empty(N)
+            lib.mg_prolongation_table(Nc, N, axis, o.ctypes.data, a.ctypes.data, b.ctypes.data)
+            assert np.array_equal(o, want), (Nc, N, axis)
+
+
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r02_bench_line.json is what bench.py printed on the MI355X: the keys the driver and the judge read must
-    be there; `roofline.frac` is PHYSICAL (compulsory bytes / time / peak, below 1), the per-sweep accounting of SURVEY 8d
-    sits beside it as `algorithmic_equiv`; the counter-measured traffic is tied to the profiled library's sha."""
+    """profiles/rNN_bench_line.json (the newest round's) is what bench.py printed on the MI355X: the keys the driver and the
+    judge read must be there; `roofline.frac` is PHYSICAL (compulsory bytes / time / peak, below 1), the per-sweep accounting
+    of SURVEY 8d sits beside it as `algorithmic_equiv`; the counter-measured traffic is tied to the profiled library's sha."""
+    import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r02_bench_line.json")))
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench_line.json")))[-1]
+    d = json.load(open(newest))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "strong_scaling", "single_sweep_roofline"):
         assert k in d, k
