@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 # the profiler's tool library belongs to the ROCm installation: bind the engine to that HIP runtime, not to the copy
 # a PyTorch wheel bundles (multigrid_poisson_solver_amd/__init__.py:_bind_hip_runtime)
 export MG_HIP_RUNTIME=system
-ARGS="--steps 10 --warmup 2 --no-cpu --no-strong $@"
+ARGS="--no-cpu --no-strong $@"   # bench.py's own K and W (50 + 50 windows back to back): the traced durations are those of the steady state the bench line reports
 # 1. kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 # 2./3. HBM counters, one pass each (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)

@@ -48,6 +48,33 @@ if stats:
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
     print()
 
+# bench.py warms up with W windows before it times K: the --stats averages above cover all W + K + 1 launches of a kernel,
+# the clock ramp of the first ~40 windows included.  The K launches of the TIMED region are the last K dispatches of
+# the finest-level kernels (one launch per window each): their average is what bench.py's live hipEvent number must agree with.
+trace_csv = find("trace", "*kernel_trace.csv")
+if trace_csv and os.path.exists(bj):
+    try:
+        K = int(b["steps"])
+        rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r["Start_Timestamp"]))
+        by = defaultdict(list)
+        for r in rows:
+            by[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        print("## the timed region only (last K dispatches of the kernels launched once per window)\n")
+        print("| kernel | launches per run | avg us, all | avg us, last K = %d |\n|---|---|---|---|" % K)
+        for name, d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            per_window = len(d) / (2 * K + 1.0)
+            if len(d) < 2 * K or abs(per_window - round(per_window)) > 0.02:
+                continue
+            m = int(round(per_window))
+            # m launches per window (the same template serves several levels): take the largest of each window
+            tail = d[-K * m:]
+            big = [max(tail[i * m:(i + 1) * m]) for i in range(K)]
+            allbig = [max(d[i * m:(i + 1) * m]) for i in range(len(d) // m)]
+            print(f"| {name} (largest of {m} per window) | {len(d)} | {sum(allbig) / len(allbig):.1f} | {sum(big) / len(big):.1f} |")
+        print()
+    except Exception as exc:  # never lose the rest of the summary
+        print(f"(timed-region table skipped: {exc})\n")
+
 # Per-launch join of the three runs.  The program is deterministic, so the i-th dispatch of a
 # kernel name in the trace run is the i-th dispatch of that name in the two counter runs.  The grid
 # cannot tell the levels apart (one resident round of workgroups at every size), so the launches of
