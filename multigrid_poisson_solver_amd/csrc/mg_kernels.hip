@@ -236,13 +236,23 @@ __global__ __launch_bounds__(1024) void k_finish(const double *__restrict__ part
 }
 
 // many doSmoothing error reductions in one launch: block b finishes descriptor b
-__global__ __launch_bounds__(256) void k_finish_batch(const NormBatch b)
+// (16 waves and four independent partial sums per thread: the finest levels leave ~8000 partials each, and this launch
+// closes every window -- 7.3 us with 256 threads and one dependent chain of loads per thread)
+__global__ __launch_bounds__(1024) void k_finish_batch(const NormBatch b)
 {
     const int d = blockIdx.x;
     const double *__restrict__ part = b.part[d];
     const int n = b.n[d], N = b.N[d];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += part[i];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        a0 += part[i];
+        a1 += part[i + 1024];
+        a2 += part[i + 2 * 1024];
+        a3 += part[i + 3 * 1024];
+    }
+    for (; i < n; i += 1024) a0 += part[i];
+    const double acc = (a0 + a1) + (a2 + a3);
     const double s = block_sum(acc);
     if (threadIdx.x == 0) {
         double e = s;
@@ -614,7 +624,7 @@ void analytic_error_rows(hipStream_t s, int N, double L, const double *U, const 
 
 void finish_smoothing_errors(hipStream_t s, const NormBatch &b, int count)
 {
-    if (count > 0) hipLaunchKernelGGL(k_finish_batch, dim3(count), dim3(256), 0, s, b);
+    if (count > 0) hipLaunchKernelGGL(k_finish_batch, dim3(count), dim3(1024), 0, s, b);
 }
 
 void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const double *F, double *out)
