@@ -380,6 +380,14 @@ def test_product_thresholds_on_the_small_and_medium_levels(mg, oracle, tmp_path)
     assert serial.returncode == 0 and sline, serial.stdout[-2000:] + serial.stderr[-3000:]
     for sp, rec in json.loads(sline[0][len("DEFAULTS_WORKER "):]).items():
         assert rec["sum"] == child[sp]["sum"] and rec["errors"] == child[sp]["errors"], f"{sp}: forked and serial W-cycle differ"
+    # ... and with two side streams only and forks from levels up to 256 (every branch then queues behind an older one on
+    # its stream, and the larger levels stay on the main line): the schedule changes, the numbers must not
+    few = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_defaults_worker.py")] + [sp for sp in specs if sp[0] == "W"],
+                         env=dict(env, MG_FORK_STREAMS="2", MG_FORK_MAX_N="256"), capture_output=True, text=True, timeout=900)
+    fline = [ln for ln in few.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
+    assert few.returncode == 0 and fline, few.stdout[-2000:] + few.stderr[-3000:]
+    for sp, rec in json.loads(fline[0][len("DEFAULTS_WORKER "):]).items():
+        assert rec["sum"] == child[sp]["sum"] and rec["errors"] == child[sp]["errors"], f"{sp}: W-cycle differs with 2 side streams"
     for spec in specs:
         kind, N, steps = spec.split(":")
         N, steps = int(N), int(steps)
