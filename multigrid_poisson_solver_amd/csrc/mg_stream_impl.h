@@ -81,7 +81,10 @@ struct StreamTables {
 
 
 constexpr int PF_DEFAULT = 2;    // rows of U and F in flight per lane (FIFO of 2*PF slots)
-constexpr int WAVES_PER_WG = 4;  // 4 adjacent strips of one chunk
+#ifndef MG_WAVES_PER_WG
+#define MG_WAVES_PER_WG 4        // (experiment switch: scripts/build_variant.sh -DMG_WAVES_PER_WG=1|2|8)
+#endif
+constexpr int WAVES_PER_WG = MG_WAVES_PER_WG;  // 4 adjacent strips of one chunk
 constexpr int MAX_S = 4;
 #ifndef MG_PF
 #define MG_PF 2   // prefetch depth of this build (scripts/build_variant.sh: -DMG_PF=3)
