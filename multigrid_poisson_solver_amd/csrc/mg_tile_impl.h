@@ -137,10 +137,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     const int yl = yb + (lane < RPW ? lane : RPW - 1);
     const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);
     // The owner cells of the fused prolongation are ADDRESS ingredients of the coarse loads: read from their tables they
-    // put a whole memory round trip in front of those loads (measured: 1.2-4 us from kernel start to the last load
-    // issued, of a ~5 us kernel).  For the level pairs of a halving hierarchy the owner is min(k*(Nc-1)/(N-1), Nc-2) in
-    // integer arithmetic -- the host checked that against the reference's ceil() tables entry by entry
-    // (ProlongTable::closed_form) -- so the kernel forms it itself; other pairs read the tables, first of all loads.
+    // put a memory round trip in front of those loads.  For the level pairs of a halving hierarchy the owner is
+    // min(k*(Nc-1)/(N-1), Nc-2) in integer arithmetic -- the host checked that against the reference's ceil() tables
+    // entry by entry (ProlongTable::closed_form) -- so the kernel forms it itself; other pairs read the tables, first of
+    // all loads.  (Measured: the 1.2-4 us from a workgroup's start to its last load issued did NOT shrink -- they are
+    // kernel arguments, instruction fetch and, at N = 1024, 62 loads per lane through the texture addressers; the closed
+    // form stays because it removes a dependent load, MG_TILE_NO_CLOSED_FORM=1 is the A/B switch.)
     int t_own = 0, cj = 0;
     if constexpr (IN == T_PROLONG) {
         if (p.own_closed) {

@@ -140,6 +140,22 @@ def test_config4_size_vs_oracle(mg, oracle, tmp_path):
         assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
     plan.close()
     mg.lib().mg_pool_trim()
+    # ... and the same size with the LIBRARY'S OWN thresholds (a child process without this suite's MG_* overrides: the
+    # configuration bench.py's strong-scaling base runs) against the oracle as well (it used to be compared
+    # with this process's run only)
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("MG_RECOMPUTE_MIN_N", "MG_NT_MIN_N", "MG_F32_COLS4_MIN_N")}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_defaults_worker.py"), str(N)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("DEFAULTS_WORKER ")]
+    assert out.returncode == 0 and line, out.stdout[-2000:] + out.stderr[-3000:]
+    child = json.loads(line[0][len("DEFAULTS_WORKER "):])[str(N)]
+    assert child["status"] == 0 and tuple(child["sum"]) == want_sum, "product thresholds at 16384^2 differ from the oracle"
+    assert child["mg_error"] == pytest.approx(want_err, rel=1e-10)
+    for g, w in zip(child["errors"], want_rec):
+        assert g == pytest.approx(w[3], rel=1e-12, abs=1e-300)
 
 
 def test_slab_mode_refuses_what_it_does_not_implement(mg, tmp_path):
