@@ -20,7 +20,10 @@ plan = mg.SlabPlan(path, R, -1, int(os.environ.get("MG_COLLAPSE_N", "1024")))
 plan.want_error(False)
 for _ in range(3):
     plan.execute()
+for _ in range(int(os.environ.get("WARM", "40")) // max(1, R if R > 1 else 1) + 4):   # sustained load first: the clocks ramp for ~30 ms
+    plan.enqueue()
 mg.sync()
+plan.collect()
 t0 = time.perf_counter()
 for _ in range(reps):
     plan.enqueue()
@@ -28,6 +31,10 @@ mg.sync()
 t1 = time.perf_counter()
 plan.collect()
 print(f"slab window (R={R}): {(t1 - t0) / reps * 1e3:.4f} ms per cycle")
+for _ in range(4):
+    plan.enqueue()
+mg.sync()
+plan.collect()
 mg.profile_begin(0)
 for _ in range(reps):
     plan.enqueue()
