@@ -62,8 +62,9 @@ def test_smoothing_fused_forms(mg, oracle, smoother, N, L):
         assert_bits(D.to_host(), oracle.getResidual(N, L, want, F), "fused +residual")
 
 
+# (66 ... 1022: sizes of the register-tile kernel -- levels 65...1024 -- that are no multiple of its tile, incl. coarse sizes that are odd)
 @pytest.mark.parametrize("N,M", [(8, 4), (16, 8), (64, 32), (100, 50), (256, 128), (1024, 512), (2048, 1024),
-                                  (33, 16), (16, 15), (100, 37), (250, 124)])
+                                  (33, 16), (16, 15), (100, 37), (250, 124), (66, 33), (72, 36), (130, 65), (514, 257), (1000, 500), (1022, 511)])
 @pytest.mark.parametrize("step", [1, 2, 3, 4, 6])
 def test_fused_smooth_restrict_vs_oracle(mg, oracle, smoother, N, M, step):
     """One "-1" node (src/MG_solver_CPU.cpp:252-287): [zero U,] smooth, residual, sign flip,
@@ -85,7 +86,7 @@ def test_fused_smooth_restrict_vs_oracle(mg, oracle, smoother, N, M, step):
 
 
 @pytest.mark.parametrize("Nc,N", [(4, 8), (8, 16), (32, 64), (50, 100), (128, 256), (512, 1024), (1024, 2048),
-                                   (16, 33), (15, 16), (37, 100), (124, 250)])
+                                   (16, 33), (15, 16), (37, 100), (124, 250), (33, 66), (36, 72), (65, 130), (257, 514), (500, 1000), (511, 1022)])
 @pytest.mark.parametrize("step", [1, 2, 3, 4, 6])
 def test_fused_prolong_smooth_vs_oracle(mg, oracle, smoother, Nc, N, step):
     """One "1" node (src/MG_solver_CPU.cpp:353-416): prolong, add, smooth."""
