@@ -186,6 +186,20 @@ def test_wcycle_forked_subcycles_back_to_back(mg, oracle, tmp_path, N, steps):
         plan.close()
 
 
+def test_wcycle_with_a_standalone_coarse_solve_does_not_fork(mg, oracle, tmp_path):
+    """A W-cycle whose coarsest level lies above the LDS tail (512 -> 256 -> 128, two exact solves at N = 128 through the
+    stand-alone solver and its device-side state): such a plan keeps every sub-cycle on the one stream (plan_forks: the
+    solver's state is shared) -- and is the oracle's bit for bit like every other file."""
+    path = str(tmp_path / "W512_128.txt")
+    assert mg.write_wcycle_file(path, 512, 128, 3, 1e-3) == 3
+    want = oracle.run_cycle_file(path)
+    plan = mg.CyclePlan(path, fused=True)
+    for _ in range(2):
+        check_against(plan.execute(fetch_U=True), want, zero_sign=True)
+    assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    plan.close()
+
+
 def test_coarse_tail_matches_node_by_node(mg, tmp_path):
     """MG_NO_TAIL=1 (read once per process) cannot be toggled here, so compare the fused driver
     (tail kernel for N <= 64) with the unfused one (operator by operator) on a deep hierarchy."""
