@@ -28,6 +28,7 @@
 // Kernel source for both field types (MG_REAL = double: mg_tile.hip; float: mg_tile_f32.hip).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -385,16 +386,28 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out)
     if (err_out) norm_finish(s, p.part, n_part, N, err_out);
 }
 
-// rows per wave: few for the smallest levels (more, shorter workgroups: the launch is pure latency), more where the
-// redundant halo rows start to cost (TY = 4 * RPW - 2 * HALO rows owned of 4 * RPW computed)
+// Window geometry: RPW rows per wave x WAVES waves.  The launch is bound by the instruction stream of a lone wave
+// (~170 instructions per row of the window for three sweeps, residual and restriction; one wave per SIMD at these grid
+// sizes), so the same window cut into MORE waves of FEWER rows is faster as long as the boundary-row exchange (two LDS
+// writes, two reads and a barrier per sweep, whatever RPW) stays small against the rows' own work:
+//   3 rows x 8 waves (24-row window) up to N = 512, 6 rows x 8 waves (48-row window) above.
+// MG_TILE_GEOM=<rpw>x<waves> forces one of 3x8, 6x4, 6x8, 12x4 (A/B switch).
 template <int S, int IN, bool RESTRICT>
 void launch_geom(hipStream_t s, const TileParams &p, double *err_out)
 {
-    static const int forced = [] { const char *e = getenv("MG_TILE_RPW"); return e ? atoi(e) : 0; }();
-    constexpr int HALO = Geom<S, IN, RESTRICT>::HALO;
-    const int rpw = forced ? forced : (p.N <= 512 ? 6 : 12);   // (measured, V(3,3): N = 512 8.2 + 7.8 us with 6 rows per wave, 9.1 + 8.5 with 12; N = 1024 equal)
-    if (rpw <= 6 && 4 * 6 - 2 * HALO >= 8) launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out);
-    else launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out);
+    static const int forced = [] {
+        const char *e = getenv("MG_TILE_GEOM");
+        if (!e) return 0;
+        int r = 0, w = 0;
+        return sscanf(e, "%dx%d", &r, &w) == 2 ? r * 100 + w : 0;
+    }();
+    const int geom = forced ? forced : (p.N <= 512 ? 308 : 608);
+    switch (geom) {
+        case 604: launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out); break;
+        case 1204: launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out); break;
+        case 608: launch_tile<S, IN, RESTRICT, 6, 8>(s, p, err_out); break;
+        default: launch_tile<S, IN, RESTRICT, 3, 8>(s, p, err_out); break;
+    }
 }
 
 template <int S>
