@@ -245,6 +245,10 @@ def test_bench_self_launches_its_ranks(mg):
     assert line["strong_scaling"]["N"] == 16384 and line["strong_scaling"]["value"] > 0
     assert 0 < line["mg_error"] < 1e-3                                     # 11520 -> ... -> 11: another hierarchy, another error
     assert line["strong_scaling"]["mg_error"] == pytest.approx(0.000883, abs=2e-6)   # the V(3,3) result of the 2^k hierarchies
+    # the line certifies its own wire: the communicator's rank count (not the environment's), where the transport came from,
+    # every rank's own clock
+    assert line["rccl"]["nranks"] == 2 and line["rccl"]["ranks_agree"] is True and "host" in line["rccl"]["transport"]
+    assert len(line["ms_per_step_ranks"]["all"]) == 2 and line["ms_per_step_ranks"]["max"] == pytest.approx(line["ms_per_step"], rel=1e-3)
 
 
 @pytest.mark.parametrize("ca_mode,ca_pct", [(0, 10), (1, 100), (2, 100), (1, 10)])
