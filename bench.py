@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STRONG_N = 16384       # BASELINE.json configs[3]: V-cycle N=16384^2, row slabs
+LARGE_N = 32768        # the same hierarchy one level up (24 GiB of level-0 arrays in fp64): where a rank of an 8-GPU run has
+                       # enough work for the latency chain of a cycle to stop capping the strong-scaling ratio
 
 
 def level_sizes(N, N_min):
@@ -269,6 +271,7 @@ def main():
     ap.add_argument("--smoother", choices=["stream", "simple"], default=os.environ.get("MG_SMOOTHER", "stream"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the N=16384 strong-scaling leg")
+    ap.add_argument("--no-large", action="store_true", help="skip the N=32768 leg (a second strong-scaling base, nested as strong_scaling_32768)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=os.environ.get("MG_BENCH_SCALING", "weak"),
                     help="which leg is the line's `value` (the other one is nested)")
     ap.add_argument("--mixed", action="store_true",
@@ -398,6 +401,25 @@ def main():
             mg.lib().mg_pool_trim()
         except mg.MGError as exc:
             out["strong_scaling"] = {"error": str(exc)}
+
+    # ---- the same one level up: N = 32768^2 fp64 (few windows: 10 ms each) ----
+    if not args.no_strong and not args.no_large and args.cycle == "V" and not args.mixed and N != LARGE_N:
+        try:
+            lcyc = os.path.join(tmp, f"Vcycle_{LARGE_N}.txt")
+            mg.write_vcycle_file(lcyc, LARGE_N, args.n_min, nu, 1e-7)
+            lsizes = level_sizes(LARGE_N, args.n_min)
+            llups = sum(2 * nu * s * s for s in lsizes[:-1])
+            lplan = mg.CyclePlan(lcyc, fused=True, report=False, error=False)
+            lsteps = min(args.steps, 10)
+            lms, _, _ = time_cycle(mg, lplan, lsteps, min(max(1, args.warmup), 10))
+            out["strong_scaling_32768"] = {"N": LARGE_N, "n_gpus": 1, "ms_per_step": round(lms, 4), "value": round(llups / (lms * 1e-3) / 1e6, 1),
+                                           "unit": "MLUPS", "steps": lsteps, "scaling": "strong",
+                                           "workload": f"V({nu},{nu})-cycle N={LARGE_N}^2 fp64, one GPU: base of a second strong-scaling curve",
+                                           "cycle_frac_of_hbm_peak": round(vcycle_compulsory_bytes(lsizes) / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            lplan.close()
+            mg.lib().mg_pool_trim()
+        except mg.MGError as exc:
+            out["strong_scaling_32768"] = {"error": str(exc)}
 
     # north_star's own yardstick, measured beside the cycle: ONE fine-level Jacobi sweep per launch (doSmoothing with
     # step = 1, 24 B per point: compulsory == algorithmic here) -- the one-row-per-block pair kernel that the engine

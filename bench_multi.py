@@ -200,6 +200,14 @@ def run(args, rank, world, local_rank):
     elif not args.no_strong:
         strong = weak  # 4 GPUs: the weak-scaling grid IS 16384^2
 
+    large = None
+    if not args.no_strong and not getattr(args, "no_large", False) and not args.mixed:
+        from bench import LARGE_N
+        import copy
+        largs = copy.copy(args)
+        largs.steps, largs.warmup = min(args.steps, 10), min(max(1, args.warmup), 10)
+        large = run_leg(mg, largs, rank, world, LARGE_N, rehearsal_wire, tmp)
+
     if rank == 0:
         head, other, name = (weak, strong, "strong_scaling")
         if args.scaling == "strong" and strong:
@@ -220,6 +228,10 @@ def run(args, rank, world, local_rank):
             out[name] = {k: other[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
                                                "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline", "ms_per_step_ranks")}
             out[name]["scaling"] = "strong" if name == "strong_scaling" else "weak"
+        if large:
+            out["strong_scaling_32768"] = {k: large[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
+                                                                 "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline", "ms_per_step_ranks")}
+            out["strong_scaling_32768"]["scaling"] = "strong"
         print(json.dumps(out), flush=True)
     if world > 1:
         mg.lib().mg_comm_finalize()

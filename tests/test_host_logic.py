@@ -198,6 +198,8 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(d["value"] - lups / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"]
     s = d["strong_scaling"]
     assert s["N"] == 16384 and s["n_gpus"] == 1 and s["value"] > 0
+    if "strong_scaling_32768" in d:   # (from round 3 on: the second strong-scaling base)
+        assert d["strong_scaling_32768"]["N"] == 32768 and d["strong_scaling_32768"]["value"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c and c["value"] > 0 and c["reps"] == 3
     assert {"makefile_flags", "one_thread"} <= set(c["variants"])
