@@ -758,6 +758,14 @@ void slab_smooth(int N, double L, const double *U_in, double *U_out, const doubl
     if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
     snprintf(name, sizeof name, "slab_stream<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
              sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
+    if (!sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps()) {
+        // a slab of a level the caches hold: the register-tile kernel on the row window (mg_tile_impl.h)
+        memcpy(name, "slab_tile  ", 11);
+        ProfScope ps(name, N, bytes);
+        k::jacobi_tile(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, -1, sf.coarse, sf.Nc, pt, sf.Fc, sf.M, rt, sf.no_out,
+                       &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
+        return;
+    }
     ProfScope ps(name, N, bytes);
     k::jacobi_stream(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, nullptr, -1, sf.coarse, sf.Nc, pt, sf.Fc,
                      sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr, sf.pre, sf.no_out);
@@ -797,6 +805,13 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
     snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
              sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
+    if (!sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps()) {
+        memcpy(name, "slab_tile  ", 11);
+        ProfScope ps(name, N, bytes);
+        k::jacobi_tile_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, -1, (const float *)sf.coarse, sf.Nc, pt,
+                           (float *)sf.Fc, sf.M, rt, sf.no_out, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
+        return;
+    }
     ProfScope ps(name, N, bytes);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, (const float *)sf.coarse,
                          sf.Nc, pt, (float *)sf.Fc, sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr,

@@ -237,13 +237,18 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
 // register-tile fused nodes of the small levels (mg_tile.hip / mg_tile_f32.hip): one launch = level 0 (zero | in | in +
 // P(coarse)), `steps` sweeps, the error norm, optionally the d_sign-ed residual restricted into Fc; whole grid only
 bool tile_wanted(int N);      // MG_TILE_MIN_N <= N <= MG_TILE_MAX_N
+bool tile_wanted_slab(int N); // the same for a launch on a row window (a slab of a distributed level): up to MG_TILE_SLAB_MAX_N
 int  tile_max_steps();
+// fine_w / coarse_w / fc_w: row windows as in jacobi_stream (nullptr = the whole grid is local); with a fine window the error
+// output is the raw sum over the counted rows
 void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out, int steps,
                  double *err_out, int d_sign, const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
-                 const RestrictTable *rt, bool no_out);
+                 const RestrictTable *rt, bool no_out, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
+                 const RowWindow *fc_w = nullptr);
 void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                      double *err_out, int d_sign, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
-                     const RestrictTable *rt, bool no_out);
+                     const RestrictTable *rt, bool no_out, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
+                     const RowWindow *fc_w = nullptr);
 void restrict_gather(hipStream_t s, int N, const double *Uf, int M, double *Uc, const RestrictTable &t, int sign);
 // Uf_out = (Uf_in ? Uf_in : 0) + P(Uc); when Uf_in == nullptr unowned fine points are left untouched
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t);

@@ -16,11 +16,19 @@ bool tile_wanted(int N)
     static const int hi = [] { const char *e = getenv("MG_TILE_MAX_N"); return e ? atoi(e) : 1024; }();
     return N >= lo && N <= hi && N >= 16;
 }
+// a slab of a distributed level is a small launch whatever the level's N: the streaming kernel's launch floor (14-15 us for
+// the 256-row slabs of a 2048 level) is what the tile kernel removes
+bool tile_wanted_slab(int N)
+{
+    static const int hi = [] { const char *e = getenv("MG_TILE_SLAB_MAX_N"); return e ? atoi(e) : 2048; }();
+    static const int lo = [] { const char *e = getenv("MG_TILE_MIN_N"); return e ? atoi(e) : 65; }();
+    return N >= lo && N <= hi && N >= 16;
+}
 int tile_max_steps() { return f64::tile::MAX_S; }
 
 void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out, int steps,
                  double *err_out, int d_sign, const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
-                 const RestrictTable *rt, bool no_out)
+                 const RestrictTable *rt, bool no_out, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w)
 {
     f64::tile::Tables tb;
     if (coarse) {
@@ -39,7 +47,7 @@ void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in,
         tb.r_w = rt->w;
         tb.r_wf = rt->inv_w;
     }
-    f64::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out);
+    f64::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out, fine_w, coarse_w, fc_w);
 }
 
 }  // namespace k

@@ -10,7 +10,7 @@ namespace k {
 
 void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                      double *err_out, int d_sign, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
-                     const RestrictTable *rt, bool no_out)
+                     const RestrictTable *rt, bool no_out, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w)
 {
     f32::tile::Tables tb;
     if (coarse) {
@@ -29,7 +29,7 @@ void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in
         tb.r_w = rt->w_f;
         tb.r_wf = rt->inv_w_f;
     }
-    f32::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out);
+    f32::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out, fine_w, coarse_w, fc_w);
 }
 
 }  // namespace k

@@ -60,6 +60,11 @@ struct TileParams {
     double *part;       // nullptr: no error norm; else one partial per wave
     long long *trace;   // MG_TILE_TRACE builds only
     int tiles_x, n_blocks;
+    // row window (1-D row-slab decomposition): the fine arrays in/F/out start at global row row_base and hold rows_local
+    // rows; this launch updates rows [own_y0, own_y1), of which [norm_y0, norm_y1) count in the error norm.  The coarse
+    // input and the coarse output have windows of their own.  Single GPU: row_base = 0, rows_local = N, own = [0, N).
+    int row_base, rows_local, own_y0, own_y1, norm_y0, norm_y1;
+    int coarse_base, coarse_rows, fc_base;
     // T_PROLONG: coarse grid and the host-built tables of doProlongation
     const real_t *coarse;
     int Nc;
@@ -113,7 +118,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int N = p.N;
-    const int oy0 = tile_y * TY, oy1 = oy0 + TY < N ? oy0 + TY : N;
+    const int oy0 = p.own_y0 + tile_y * TY, oy1 = oy0 + TY < p.own_y1 ? oy0 + TY : p.own_y1;
+    // rows that exist in the local window and in the grid (loads are clamped to them; a slab's window holds its rows
+    // +- the halo its schedule promised, which is what this kernel reads: own +- HALO)
+    const int av_lo = p.row_base > 0 ? p.row_base : 0;
+    const int av_hi = p.row_base + p.rows_local < N ? p.row_base + p.rows_local : N;
     const int ox0 = tile_x * TX, ox1 = ox0 + TX < N ? ox0 + TX : N;
     const int x = ox0 - HALO + lane;        // this lane's column
     const int yb = oy0 - HALO + wave * RPW; // first row of this wave's block
@@ -129,14 +138,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     const bool want_res = RESTRICT || p.part != nullptr;
 
     auto row_y = [&](int j) { return yb + j; };
-    auto row_clamped = [&](int j) { const int y = yb + j; return y < 0 ? 0 : (y < N ? y : N - 1); };
+    auto row_clamped = [&](int j) { const int y = yb + j; return (y < av_lo ? av_lo : (y < av_hi ? y : av_hi - 1)) - p.row_base; };  // LOCAL row
     auto row_inner = [&](int j) { return ((unsigned)(yb + j - 1) < (unsigned)(N - 2)) ? -1 : 0; };  // 0 on the rim rows and outside
     auto row_owned = [&](int j) { return (unsigned)(yb + j - oy0) < (unsigned)(oy1 - oy0); };
 
     // ---- every load of the node, issued in one batch ---------------------------------------------------------------
     // wave-uniform per-row table entries ride in one register per table, row j of the block in lane j (v_readlane)
     const int yl = yb + (lane < RPW ? lane : RPW - 1);
-    const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);
+    const int ylc = yl < 0 ? 0 : (yl < N ? yl : N - 1);   // (tables are indexed by the GLOBAL row)
     // The owner cells of the fused prolongation are ADDRESS ingredients of the coarse loads: read from their tables they
     // put a memory round trip in front of those loads.  For the level pairs of a halving hierarchy the owner is
     // min(k*(Nc-1)/(N-1), Nc-2) in integer arithmetic -- the host checked that against the reference's ceil() tables
@@ -169,6 +178,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
 #pragma unroll
         for (int j = 0; j < RPW; ++j) v[j] = p.in[(size_t)row_clamped(j) * N + xc];
     }
+    // local row of the coarse window (rows fetched for halo rows of the fine window may lie outside it: clamped, never consumed)
+    auto coarse_local = [&](int r) { const int l = r - p.coarse_base; return l < 0 ? 0 : (l < p.coarse_rows - 1 ? l : p.coarse_rows - 1); };
     real_t t_rhi = 0, t_rlo = 0, pc_hi = 0, pc_lo = 0;
     real_t ca[RPW], cb[RPW], c0a = 0, c0b = 0;
     int own[RPW];
@@ -185,11 +196,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
         for (int j = 0; j < RPW; ++j) {
             own[j] = lane_value(t_own, j);
             const int up = own[j] + 1 < last ? own[j] + 1 : last;
-            const real_t *crow = p.coarse + (size_t)up * p.Nc;
+            const real_t *crow = p.coarse + (size_t)coarse_local(up) * p.Nc;
             ca[j] = crow[cj];
             cb[j] = crow[cj1];
         }
-        const real_t *crow0 = p.coarse + (size_t)own[0] * p.Nc;
+        const real_t *crow0 = p.coarse + (size_t)coarse_local(own[0]) * p.Nc;
         c0a = crow0[cj];
         c0b = crow0[cj1];
     }
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     if (!p.no_out && lane_owns) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j)
-            if (row_owned(j)) p.out[(size_t)row_y(j) * N + x] = v[j];
+            if (row_owned(j)) p.out[(size_t)(row_y(j) - p.row_base) * N + x] = v[j];
     }
 
     // ---- residual (:560), error sums (:610/:617), restriction (:656-678) -------------------------------------------
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
             const real_t r = inv * minus4(nw + so + e + w, c) - f[j];
             const int inner = row_inner(j);
             if constexpr (RESTRICT) d[j] = r * hi_bits_and(ms, inner);  // sign flip :277-280 and the zero rim in one exact product
-            const int am = ((j & 1) ? nm_odd : nm_even) & (row_owned(j) ? inner : 0);
+            const int am = ((j & 1) ? nm_odd : nm_even) & ((row_owned(j) && (unsigned)(yb + j - p.norm_y0) < (unsigned)(p.norm_y1 - p.norm_y0)) ? inner : 0);
             acc += fabs(bits_and((double)r, am));
         }
         if (p.part) {
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
             if (wave == 0) {
                 for (int edge = 0; edge < 2; ++edge) {
                     if (edge == 0 ? (oy0 != 0) : (oy1 != N)) continue;
-                    real_t *row = p.Fc + (size_t)(edge == 0 ? 0 : p.M - 1) * p.M;
+                    real_t *row = p.Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
                     if (rc_col >= 0) row[rc_col] = 0.0;
                     if (first_col_lane) row[0] = 0.0;
                     if (last_col_lane) row[p.M - 1] = 0.0;
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
                 const real_t u1 = from_lane_above(u0), u3 = from_lane_above(u2);
                 // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
                 const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
-                real_t *crow = p.Fc + (size_t)rc_row * p.M;
+                real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
                 if (rc_col >= 0) crow[rc_col] = vc;
                 if (tile_x == 0 && first_col_lane) crow[0] = 0.0;
                 if (ox1 == N && last_col_lane) crow[p.M - 1] = 0.0;
@@ -352,12 +363,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
 
 // geometry of one instantiation, for the launcher
 template <int S, int IN, bool RESTRICT, int RPW, int WAVES>
-void launch_tile(hipStream_t s, TileParams p, double *err_out)
+void launch_tile(hipStream_t s, TileParams p, double *err_out, bool raw_norm)
 {
     constexpr int HALO = Geom<S, IN, RESTRICT>::HALO, TY = RPW * WAVES - 2 * HALO, TX = Geom<S, IN, RESTRICT>::TX;
     const int N = p.N;
+    const int own = p.own_y1 - p.own_y0;
+    if (own <= 0) return;
     p.tiles_x = (N + TX - 1) / TX;
-    const int tiles_y = (N + TY - 1) / TY;
+    const int tiles_y = (own + TY - 1) / TY;
     p.n_blocks = p.tiles_x * tiles_y;
     p.part = nullptr;
     const size_t n_part = (size_t)p.n_blocks * WAVES;
@@ -383,7 +396,8 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out)
                 (t[5] - t[4]) * 0.01);
     }
 #endif
-    if (err_out) norm_finish(s, p.part, n_part, N, err_out);
+    // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
+    if (err_out) norm_finish(s, p.part, n_part, raw_norm ? -1 : N, err_out);
 }
 
 // Window geometry: RPW rows per wave x WAVES waves.  The launch is bound by the instruction stream of a lone wave
@@ -393,7 +407,7 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out)
 //   3 rows x 8 waves (24-row window) up to N = 512, 6 rows x 8 waves (48-row window) above.
 // MG_TILE_GEOM=<rpw>x<waves> forces one of 3x8, 6x4, 6x8, 12x4 (A/B switch).
 template <int S, int IN, bool RESTRICT>
-void launch_geom(hipStream_t s, const TileParams &p, double *err_out)
+void launch_geom(hipStream_t s, const TileParams &p, double *err_out, bool raw_norm)
 {
     static const int forced = [] {
         const char *e = getenv("MG_TILE_GEOM");
@@ -403,25 +417,25 @@ void launch_geom(hipStream_t s, const TileParams &p, double *err_out)
     }();
     const int geom = forced ? forced : (p.N <= 512 ? 308 : 608);
     switch (geom) {
-        case 604: launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out); break;
-        case 1204: launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out); break;
-        case 608: launch_tile<S, IN, RESTRICT, 6, 8>(s, p, err_out); break;
-        default: launch_tile<S, IN, RESTRICT, 3, 8>(s, p, err_out); break;
+        case 604: launch_tile<S, IN, RESTRICT, 6, 4>(s, p, err_out, raw_norm); break;
+        case 1204: launch_tile<S, IN, RESTRICT, 12, 4>(s, p, err_out, raw_norm); break;
+        case 608: launch_tile<S, IN, RESTRICT, 6, 8>(s, p, err_out, raw_norm); break;
+        default: launch_tile<S, IN, RESTRICT, 3, 8>(s, p, err_out, raw_norm); break;
     }
 }
 
 template <int S>
-void launch_steps(hipStream_t s, const TileParams &p, double *err_out)
+void launch_steps(hipStream_t s, const TileParams &p, double *err_out, bool raw_norm)
 {
     const bool restrict_out = p.Fc != nullptr, prolong_in = p.coarse != nullptr, zero = p.in == nullptr;
     if (restrict_out) {
-        if (zero) launch_geom<S, T_ZERO, true>(s, p, err_out);
-        else launch_geom<S, T_LOAD, true>(s, p, err_out);
+        if (zero) launch_geom<S, T_ZERO, true>(s, p, err_out, raw_norm);
+        else launch_geom<S, T_LOAD, true>(s, p, err_out, raw_norm);
     } else if (prolong_in) {
-        launch_geom<S, T_PROLONG, false>(s, p, err_out);
+        launch_geom<S, T_PROLONG, false>(s, p, err_out, raw_norm);
     } else {
-        if (zero) launch_geom<S, T_ZERO, false>(s, p, err_out);
-        else launch_geom<S, T_LOAD, false>(s, p, err_out);
+        if (zero) launch_geom<S, T_ZERO, false>(s, p, err_out, raw_norm);
+        else launch_geom<S, T_LOAD, false>(s, p, err_out, raw_norm);
     }
 }
 
@@ -439,7 +453,8 @@ constexpr int MAX_S = 4;
 // one fused node on the whole grid: same contract as the streaming kernel's entry point without row windows, without a
 // stored residual and without the recomputing form (the caller routes those to the streaming kernel)
 inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps, double *err_out,
-                int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M, const Tables &tb, bool no_out)
+                int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M, const Tables &tb, bool no_out,
+                const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr)
 {
     if (steps < 1 || steps > MAX_S || N < 8) {
         fail(MG_ERR_ARG, "jacobi_tile: %d sweeps on N=%d (1..%d sweeps, N >= 8)", steps, N, MAX_S);
@@ -458,7 +473,16 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
     p.out = out;
     p.no_out = no_out ? 1 : 0;
     p.d_sign = d_sign;
+    p.row_base = fine_w ? fine_w->base : 0;
+    p.rows_local = fine_w ? fine_w->rows : N;
+    p.own_y0 = fine_w ? fine_w->own_lo : 0;
+    p.own_y1 = fine_w ? fine_w->own_hi : N;
+    p.norm_y0 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_lo : p.own_y0;
+    p.norm_y1 = fine_w && fine_w->norm_lo >= 0 ? fine_w->norm_hi : p.own_y1;
+    p.coarse_rows = 1;
     if (coarse) {
+        p.coarse_base = coarse_w ? coarse_w->base : 0;
+        p.coarse_rows = coarse_w ? coarse_w->rows : Nc;
         p.coarse = coarse;
         p.Nc = Nc;
         p.p_orow = tb.p_orow;
@@ -474,17 +498,19 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         p.own_rcp = 1.0f / (float)(N - 1);
     }
     if (Fc) {
+        p.fc_base = fc_w ? fc_w->base : 0;
         p.Fc = Fc;
         p.M = M;
         p.r_inv = tb.r_inv;
         p.r_w = tb.r_w;
         p.r_wf = tb.r_wf;
     }
+    const bool raw_norm = fine_w != nullptr;
     switch (steps) {
-        case 1: launch_steps<1>(s, p, err_out); break;
-        case 2: launch_steps<2>(s, p, err_out); break;
-        case 3: launch_steps<3>(s, p, err_out); break;
-        default: launch_steps<4>(s, p, err_out); break;
+        case 1: launch_steps<1>(s, p, err_out, raw_norm); break;
+        case 2: launch_steps<2>(s, p, err_out, raw_norm); break;
+        case 3: launch_steps<3>(s, p, err_out, raw_norm); break;
+        default: launch_steps<4>(s, p, err_out, raw_norm); break;
     }
 }
 
