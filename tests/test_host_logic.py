@@ -172,6 +172,23 @@ def test_recompute_pair_and_closed_form_owner_predicates(m):
             assert np.array_equal(o, want), (Nc, N, axis)
 
 
+def test_bench_accounting_helpers():
+    """bench.py's byte and update counts: a V-cycle visits every level once, the W-cycle of the shipped
+    recursion visits level l >= 1 2^l times; the W-cycle's compulsory bytes are the per-level terms weighted by the visits."""
+    sys.path.insert(0, ROOT)
+    import bench
+    sizes = bench.level_sizes(8192, 8)
+    assert sizes == [8192 >> l for l in range(11)]
+    assert bench.level_visits(sizes, "V") == [1] * 11
+    assert bench.level_visits(sizes, "W") == [1] + [2 ** l for l in range(1, 11)]
+    v = bench.vcycle_compulsory_bytes(sizes)
+    w = bench.vcycle_compulsory_bytes(sizes, visits=bench.level_visits(sizes, "W"))
+    # recomputing pair (levels >= MG_RECOMPUTE_MIN_N: 4096 in the product, lower in this suite): 24 n + 16 m; 40 n + 16 m below; nothing for the LDS tail
+    assert v == pytest.approx(sum((24.0 if a >= bench.RECOMPUTE_MIN_N else 40.0) * a * a + 16.0 * (a // 2) ** 2 for a in sizes[:-1] if a > 64))
+    assert v < w < 2.0 * v   # (the geometric sum of 2^l / 4^l)
+    assert bench.vcycle_algorithmic_bytes(sizes, 3, 3) == pytest.approx(sum(200.0 * a * a + 16.0 * (a // 2) ** 2 for a in sizes[:-1]))
+
+
 def test_committed_bench_line_keeps_the_contract():
     """profiles/rNN_bench_line.json (the newest round's) is what bench.py printed on the MI355X: the keys the driver and the
     judge read must be there; `roofline.frac` is PHYSICAL (compulsory bytes / time / peak, below 1), the per-sweep accounting
