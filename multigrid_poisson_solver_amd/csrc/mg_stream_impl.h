@@ -282,8 +282,35 @@ struct WavesPerSimd {
     static constexpr int min = (MG_WPE_DOWN > 0 && sizeof(real_t) == 8 && COLS == 2 && IN == 1 /* IN_ZERO */ && RESTRICT && S <= 3) ? MG_WPE_DOWN : 1;
 };
 
+// Round 4: the recomputing `1` node keeps its F rows in LDS instead of in a register ring (MG_LDS_RING, A/B switch).
+// A row of F lives PF + L + 2 = 10 steps; as registers that was a ring of 16 slots = 64 VGPRs of the 249 that held the
+// kernel to two waves per SIMD with the LDS of the CU idle.  Now a row is loaded PF steps ahead into a short register
+// FIFO and, when it arrives, goes to the wave's own slice of LDS TWICE: dx2*F (what the L sweeps consume: the product
+// is formed once per point instead of once per point and sweep -- the same rounding, hence the same bits) in a ring of 8
+// rows x 16 B per lane, and the ONE column of the row the error norm will look at (see HALF below) in a ring of 8 rows
+// x 8 B per lane: 12 KiB per wave, 144 KiB for the 12 waves of a CU at three waves per SIMD.  No barrier: a wave only
+// ever touches its own slice, and the LDS operations of one wave execute in order.  The ring slots are compile-time
+// offsets of the ds_read/ds_write instructions (the loop body covers 8 steps = one turn of the ring).
+// HALF: doSmoothing's error norm (src/MG_solver_CPU.cpp:610/:617) counts the interior points with (row + col) even only,
+// and this node stores no residual, so the residual stage forms ONE column per row: the pipeline starts on an even row
+// (a chunk that begins on an odd row marches one row more), which makes the parity of every row a compile-time property
+// of its position in the loop body.  The sum gets the very terms it got before (the masked column contributed +0.0).
+#ifndef MG_LDS_RING
+#define MG_LDS_RING 1
+#endif
+template <int COLS, int PRE>
+struct LdsRing {
+    static constexpr bool value = MG_LDS_RING && PRE > 0 && COLS == 2;
+};
+#ifndef MG_PF_UP
+#define MG_PF_UP 3    // rows of F (and coarse rows) in flight per lane in the LDS-ring form of the `1` node
+#endif
+#ifndef MG_WPE_UP
+#define MG_WPE_UP 2   // (3 = 168 VGPRs: the allocator spills 15-27 dwords, and a spill reload drains the load queue: 580 us)   waves per SIMD the allocator is asked to make room for in the LDS-ring form of the `1` node
+#endif
+
 template <int S, int COLS, int IN, bool RESTRICT, int PF = PF_DEFAULT, bool NT = false, int PRE = 0>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(WavesPerSimd<S, COLS, IN, RESTRICT, PRE>::min)))
+__global__ __launch_bounds__(64 * WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(LdsRing<COLS, PRE>::value ? MG_WPE_UP : WavesPerSimd<S, COLS, IN, RESTRICT, PRE>::min)))
 void k_jacobi_stream(const StreamParams p)
 {
     static_assert(COLS == 2 || COLS == 4 || (IN != IN_PROLONG && !RESTRICT), "fused transfer stages need column pairs");
@@ -296,8 +323,18 @@ void k_jacobi_stream(const StreamParams p)
     // read here, 8 B per point less to write there, for PRE more sweeps of arithmetic in a kernel that waits for memory.
     static_assert(PRE == 0 || (IN == IN_PROLONG && !RESTRICT), "recomputed pre-smoothing belongs to the fused `1` node");
     constexpr int L = S + PRE;                         // levels of the pipeline
-    constexpr int NB = PF + L + 2 <= 8 ? 8 : 16;       // slots of the F ring = row steps of the loop body
-    static_assert(PF + L + 2 <= NB && PF < 4, "the F ring has NB slots, the U ring 4");
+    constexpr bool LDSR = LdsRing<COLS, PRE>::value;   // F rows in LDS (dx2*F for the sweeps, one column of F for the norm)
+    constexpr bool HALF = LDSR;                        // norm-only residual stage: one column per row
+#ifndef MG_TB_DIRECT
+#define MG_TB_DIRECT 0
+#endif
+    constexpr bool TB_DIRECT = LDSR && MG_TB_DIRECT;   // table blocks loaded where they take over (no second set of registers)
+    constexpr int NB = LDSR ? 8 : (PF + L + 2 <= 8 ? 8 : 16);  // slots of the F ring = row steps of the loop body
+    constexpr int NFR = LDSR ? 4 : NB;                 // F rows held in registers (LDSR: the rows in flight only)
+    static_assert((LDSR ? L + 2 <= NB : PF + L + 2 <= NB) && PF < 4, "the F ring has NB slots, the U ring 4");
+    static_assert(!LDSR || (IN == IN_PROLONG && !RESTRICT), "the LDS ring belongs to the recomputing `1` node");
+    __shared__ real2_t s_g[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];   // dx2*F, rows yin-L .. yin
+    __shared__ real_t s_f[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];    // F of the column the norm counts
     constexpr int W = 64 * COLS;
     constexpr int H = Halo<L, RESTRICT, COLS>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
@@ -455,8 +492,9 @@ void k_jacobi_stream(const StreamParams p)
 #pragma unroll
     for (int j = 0; j < COLS; ++j) ms[j] = col_edge[j] ? real_t(0.0) : (p.d_sign < 0 ? real_t(-1.0) : real_t(1.0));
 
-    const int y_first = y0 - (L + 1);                             // first input row
-    const int T = (y1 - y0) + 2 * (L + 1) + (RESTRICT ? 1 : 0);   // input rows consumed
+    const int y0e = HALF ? (y0 & ~1) : y0;                        // HALF: the march starts on an even row
+    const int y_first = y0e - (L + 1);                            // first input row
+    const int T = (y1 - y0e) + 2 * (L + 1) + (RESTRICT ? 1 : 0);  // input rows consumed
     const int y_end = y_first + T;                                // one past the last input row
 
     // ---- wave-uniform per-row table entries: ONE REGISTER PER TABLE, one row per lane.  Lane L of a block holds the
@@ -466,7 +504,6 @@ void k_jacobi_stream(const StreamParams p)
     //   prolongation: owner coarse row (needed PF steps ahead, for the coarse prefetch) and the two row weights;
     //   restriction: coarse row sampled at fine row (input row - S - 2) and its weight c.
     int tb_own = -1, tbn_own = -1;                          // block of the row being PREFETCHED (step + PF)
-    int tb_crow = 0, tbn_crow = 0;                          // ... and the local index of the coarse row (owner + 1), clamped
     real_t tb_yh = 0.0, tb_yl = 0.0, tbn_yh = 0.0, tbn_yl = 0.0;  // block of the row being consumed
     int tb_rc = -1, tbn_rc = -1;
     real_t tb_rw = 0.0, tbn_rw = 0.0;
@@ -476,9 +513,6 @@ void k_jacobi_stream(const StreamParams p)
         const int yc = y < 0 ? 0 : (y < N ? y : N - 1);
         const int v = p.p_orow[yc];
         tbn_own = ok ? v : -1;
-        // rows fetched ahead of need may lie outside the local window of the coarse array: clamped, never consumed
-        const int r = tbn_own + 1 - p.coarse_base;
-        tbn_crow = r < 0 ? 0 : (r < p.coarse_rows - 1 ? r : p.coarse_rows - 1);
     };
     auto load_weight_block = [&](int first_row) {  // -> tbn_yh, tbn_yl
         const int y = first_row + lane;
@@ -501,7 +535,6 @@ void k_jacobi_stream(const StreamParams p)
     if constexpr (IN == IN_PROLONG) {
         load_own_block(yp_first);
         tb_own = tbn_own;
-        tb_crow = tbn_crow;
         load_weight_block(yp_first);
         tb_yh = tbn_yh;
         tb_yl = tbn_yl;
@@ -522,11 +555,11 @@ void k_jacobi_stream(const StreamParams p)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
     constexpr int NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
-    Row<COLS> fr[NB], pu[NU];
+    Row<COLS> fr[NFR], pu[NU];
     CoarseV<NCV> pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
     int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
+    for (int k = 0; k < NFR; ++k)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) fr[k].v[j] = 0.0;
 #pragma unroll
@@ -536,6 +569,16 @@ void k_jacobi_stream(const StreamParams p)
 #pragma unroll
         for (int q = 0; q < NCV; ++q) pc[k].v[q] = 0.0;
         q_own[k] = -1;
+    }
+
+    if constexpr (LDSR) {  // (rows before the first arrival are read by pipeline levels nobody consumes: keep them finite)
+        real2_t z;
+        z.x = z.y = real_t(0.0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            s_g[wave][k][lane] = z;
+            s_f[wave][k][lane] = real_t(0.0);
+        }
     }
 
     // wave-uniform row addresses, in bytes.  The load address follows the CLAMPED input row (every load is issued, see
@@ -551,12 +594,17 @@ void k_jacobi_stream(const StreamParams p)
     // issue the loads of input row y_first + ld_t into their ring slots (u8 = ld_t % 8, compile-time at every call)
     auto fetch = [&](int u8) {
         if constexpr (IN != IN_ZERO && PRE == 0) pu[u8 % NU] = load_row<COLS, (MG_NT_LOADS >= 2)>(reinterpret_cast<const real_t *>(in_b + ld_off), col_off);
-        fr[u8] = load_row<COLS, (MG_NT_LOADS >= 1)>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
+        fr[u8 % NFR] = load_row<COLS, (MG_NT_LOADS >= 1)>(reinterpret_cast<const real_t *>(f_b + ld_off), col_off);
         if constexpr (IN == IN_PROLONG) {
             // the UPPER coarse row of this input row travels with it, so every vector load of the loop is issued at
             // a fixed place PF steps before its use
-            q_own[u8 % NU] = lane_value(tb_own, ld_t & 63);
-            pc[u8 % NU] = load_coarse_local<NCV>(p.coarse, p.Nc, lane_value(tb_crow, ld_t & 63), pc_col);
+            const int own_s = lane_value(tb_own, ld_t & 63);
+            q_own[u8 % NU] = own_s;
+            // local index of the coarse row (owner + 1), clamped to the window: rows fetched ahead of need may lie outside it
+            // (never consumed).  Scalar arithmetic on the wave-uniform owner (a second table register cost two VGPRs)
+            const int cr = own_s + 1 - p.coarse_base;
+            const int crc = cr < 0 ? 0 : (cr < p.coarse_rows - 1 ? cr : p.coarse_rows - 1);
+            pc[u8 % NU] = load_coarse_local<NCV>(p.coarse, p.Nc, crc, pc_col);
         }
         ++ld_t;
         // the clamped row moves on only inside the window: av_lo < y_first + ld_t < av_hi
@@ -579,6 +627,11 @@ void k_jacobi_stream(const StreamParams p)
 #ifdef MG_STREAM_TRACE
     const long long tr1 = wall_clock64();
 #endif
+    Row<COLS> gq[L + 1];   // LDS ring: dx2*F of the rows the levels of the coming step consume (zero before the first arrival)
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) gq[l].v[j] = 0.0;
     double acc = 0.0;
     const unsigned rows_own = (unsigned)(y1 - y0), rows_norm = (unsigned)(p.norm_y1 - p.norm_y0);
     // the loop body covers 8 rows, so the parity of the residual row is a compile-time property of the position in
@@ -597,13 +650,16 @@ void k_jacobi_stream(const StreamParams p)
         // table blocks: (t0 & 63) == 56 -> load the blocks that start 8 steps from now; == 0 -> they take over.
         // The owner block runs PF steps ahead of the others (it serves the prefetch), so it switches inside the body.
         if ((t0 & 63) == 64 - NB) {
-            if constexpr (IN == IN_PROLONG) {
+            if constexpr (IN == IN_PROLONG && !TB_DIRECT) {
                 load_own_block(yp_first + t0 + NB);
                 load_weight_block(yp_first + t0 + NB);
             }
             if constexpr (RESTRICT) load_restrict_block(y_first + t0 + NB - (L + 2));
         }
         if ((t0 & 63) == 0 && t0 > 0) {
+            if constexpr (IN == IN_PROLONG && TB_DIRECT) {
+                load_weight_block(yp_first + t0);
+            }
             if constexpr (IN == IN_PROLONG) {
                 tb_yh = tbn_yh;
                 tb_yl = tbn_yl;
@@ -618,7 +674,9 @@ void k_jacobi_stream(const StreamParams p)
         auto row_step = [&](auto k_tag) -> bool {
             constexpr int k = decltype(k_tag)::value;
             const int t = t0 + k;
-            if (k > 0 && t >= T) return false;  // (small levels: a chunk is a dozen rows, not a multiple of 8)
+            // (small levels: a chunk is a dozen rows, not a multiple of 8.  The LDS-ring form runs on big levels only, its
+            // launcher makes a chunk's march a multiple of 8 steps, and steps past the end load clamped rows and store nothing)
+            if (!LDSR && k > 0 && t >= T) return false;
             const int yin = y_first + t;
             Row<COLS> nw;
             if constexpr (IN == IN_ZERO || PRE > 0) {
@@ -628,12 +686,22 @@ void k_jacobi_stream(const StreamParams p)
                 nw = pu[k % NU];
             }
             const int own_i = q_own[k % NU];
-            const CoarseV<NCV> own_up = pc[k % NU];
             if constexpr (IN == IN_PROLONG) {
                 // the prefetch below reads the owner of row t + PF: from step 64 m - PF on that is the next block
                 if (k == NB - PF && (t0 & 63) == 64 - NB) {
+                    if constexpr (TB_DIRECT) load_own_block(yp_first + t0 + NB);
                     tb_own = tbn_own;
-                    tb_crow = tbn_crow;
+                }
+                // the coarse row that came with this step's input is consumed AT ONCE (it feeds the horizontal interpolants
+                // hA / hB only), so its registers are free again for the prefetch that follows
+                if (own_i >= 0 && own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
+                    // (kept a wave-uniform BRANCH: if-converted, the rotation costs its selects and the interpolation
+                    // on every row instead of on every other one)
+                    asm volatile("" ::);
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) hA[j] = hB[j];
+                    c_row = own_i;
+                    interpolate(pc[k % NU], hB);  // row own_i + 1, loaded PF iterations ago
                 }
             }
             fetch((k + PF) % NB);  // the row PF ahead, into the slots whose rows were retired (k + PF - 8 resp. k - PF)
@@ -642,15 +710,6 @@ void k_jacobi_stream(const StreamParams p)
             // prolongation belongs to -- the input row (PRE == 0) or level PRE's row yin - PRE.  own_i is wave-uniform.
             auto add_prolongation = [&](Row<COLS> &row) {
                 if (own_i >= 0) {
-                    if (own_i != c_row) {  // the owner row advanced by one (host-checked): rotate
-                        // (kept a wave-uniform BRANCH: if-converted, the rotation costs its selects and the interpolation
-                        // on every row instead of on every other one)
-                        asm volatile("" ::);
-#pragma unroll
-                        for (int j = 0; j < COLS; ++j) hA[j] = hB[j];
-                        c_row = own_i;
-                        interpolate(own_up, hB);  // row own_i + 1, loaded PF iterations ago
-                    }
                     const real_t own_yh = lane_value(tb_yh, t & 63), own_yl = lane_value(tb_yl, t & 63);
                     const real_t c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
 #pragma unroll
@@ -669,7 +728,15 @@ void k_jacobi_stream(const StreamParams p)
                 const int y = yin - l;
                 const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;  // 0 on the rim rows 0 and N-1
                 const Row<COLS> c = newer[l - 1], so = older[l - 1];
-                const Row<COLS> &f = fr[(k - l + NB) % NB];
+                // dx2*F of row yin - l: from the LDS ring (formed once, when the row arrived), or formed here
+                Row<COLS> g;
+                if constexpr (LDSR) {
+                    g = gq[l];   // requested at the end of the previous step
+                } else {
+                    const Row<COLS> &f = fr[(k - l + NB) % NB];
+#pragma unroll
+                    for (int j = 0; j < COLS; ++j) g.v[j] = dx2 * f.v[j];
+                }
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> o;
@@ -681,7 +748,7 @@ void k_jacobi_stream(const StreamParams p)
                         for (int j = 0; j < COLS; ++j) {
                             // q*(0 - dx2*F) + 0: `0 - p` is -p exactly, and whichever zero the product is, adding +0 gives +0:
                             // the negation rides on the fma's operand instead of costing a subtraction
-                            o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), -(dx2 * f.v[j]), real_t(0.0));
+                            o.v[j] = fused_mul_add(hi_bits_and(qc[j], inner), -g.v[j], real_t(0.0));
                         }
                         older[l - 1] = c;
                         newer[l - 1] = nw;
@@ -698,7 +765,7 @@ void k_jacobi_stream(const StreamParams p)
                     const real_t e = j == COLS - 1 ? east_last : c.v[j < COLS - 1 ? j + 1 : 0];
                     // src/MG_solver_CPU.cpp:590: U += 0.25*(U[i+1]+U[i-1]+U[j+1]+U[j-1] - 4U - dx^2 F)
                     // `- 4*U` through one fma: 4*U is exact, so fma(-4, U, a) is the same bits as a - 4*U (one VALU op less)
-                    const real_t t4 = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - dx2 * f.v[j];
+                    const real_t t4 = minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - g.v[j];
                     // `U + 0.25*t` through one fma as well: the product with a power of two is exact, so the fused form
                     // rounds once exactly like the sum does; with q = 0 on the rim (row or column) the point keeps its
                     // value, which replaces the rim selects
@@ -709,6 +776,26 @@ void k_jacobi_stream(const StreamParams p)
                 nw = o;
                 if constexpr (IN == IN_PROLONG && PRE > 0) {
                     if (l == PRE) add_prolongation(nw);  // nw: the pre-smoothed row yin - PRE, as the `-1` node had it
+                }
+            }
+
+            if constexpr (LDSR) {
+                // the F row of THIS step (issued PF steps ago) goes to the rings; level 1 reads it in the next step.
+                // Row yin has the parity of k + L + 1 (the march starts on an even row): an even row counts its even column
+                const Row<COLS> &fin = fr[k % NFR];
+                real2_t t;
+                t.x = dx2 * fin.v[0];
+                t.y = dx2 * fin.v[1];
+                s_g[wave][k % NB][lane] = t;
+                s_f[wave][k % NB][lane] = fin.v[(k + L + 1) & 1];
+                // ... and the rows of dx2*F the L levels of the NEXT step consume are requested now (level 1's is the row just
+                // written: the LDS operations of a wave execute in order), so their round trips lie under this step's tail
+                // and the next step's head instead of in front of every level
+#pragma unroll
+                for (int l = 1; l <= L; ++l) {
+                    const real2_t r = s_g[wave][(k + 1 - l + 2 * NB) % NB][lane];
+                    gq[l].v[0] = r.x;
+                    gq[l].v[1] = r.y;
                 }
             }
 
@@ -749,7 +836,21 @@ void k_jacobi_stream(const StreamParams p)
                 const int inner = ((unsigned)(y - 1) < (unsigned)(N - 2)) ? -1 : 0;
                 const int cm = (mine_row && (unsigned)(y - p.norm_y0) < rows_norm) ? inner : 0;  // -1: the row counts
                 const Row<COLS> c = newer[L], so = older[L];
-                const Row<COLS> &f = fr[(k - L - 1 + NB) % NB];
+                if constexpr (HALF) {
+                    // norm only: row y has the parity of k, its counted column is j = k & 1 (xl is even)
+                    constexpr int j = k & 1;
+                    const real_t fv = s_f[wave][(k - L - 1 + 2 * NB) % NB][lane];
+                    const real_t w = j == 0 ? from_lane_below(c.v[1]) : c.v[0];
+                    const real_t e = j == 0 ? c.v[1] : from_lane_above(c.v[0]);
+                    const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - fv;
+                    const int am = ((lane_owns && !col_edge[j]) ? -1 : 0) & cm;
+                    acc += fabs(bits_and((double)r, am));
+                    older[L] = newer[L];
+                    newer[L] = nw;
+                    st_off += row_bytes;
+                    return true;
+                }
+                const Row<COLS> &f = fr[(k - L - 1 + 2 * NB) % NFR];
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> d;
@@ -841,6 +942,7 @@ void k_jacobi_stream(const StreamParams p)
     }
 }
 
+#ifndef MG_STREAM_KERNEL_ONLY   // (register experiments compile single instantiations of the kernel without the launchers)
 // One launch: tile the grid for ONE resident round of workgroups (measured occupancy of
 // this instantiation x CUs) where the grid is large enough, never fewer than 8 rows per
 // chunk (each chunk re-reads 2(S+1) halo rows), then the fixed-order error reduction.
@@ -874,6 +976,12 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     int rows = (own + chunks - 1) / chunks;
     static const int rows_cap = [] { const char *e = getenv("MG_MAX_ROWS"); return e ? atoi(e) : 0; }();
     if (rows_cap > 0 && rows > rows_cap) rows = rows_cap;  // tuning knob: more, shorter tiles
+    if (LdsRing<COLS, PRE>::value) {
+        // even (the norm-only residual stage starts every chunk on an even row) and a march of rows + 2 (L + 1) steps that
+        // is a multiple of the 8-step loop body (which has no exit inside)
+        const int march = rows + 2 * (S + PRE + 1);
+        rows += (8 - march % 8) % 8;
+    }
     chunks = (own + rows - 1) / rows;
     p.rows_per_chunk = rows;
     p.groups = groups;
@@ -969,8 +1077,10 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
     } else if (prolong_in) {
         if constexpr (recompute_instantiated(S, S) && PF == 2) {
             if (p.pre == S) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
-                if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true, S>(s, p, err_out);
-                else launch_k<S, 2, IN_PROLONG, false, PF, false, S>(s, p, err_out);
+                // (rows in flight: with the F ring in LDS the registers for a deeper prefetch are there, MG_PF_UP)
+                constexpr int PFU = LdsRing<2, S>::value ? MG_PF_UP : PF;
+                if (nt) launch_k<S, 2, IN_PROLONG, false, PFU, true, S>(s, p, err_out);
+                else launch_k<S, 2, IN_PROLONG, false, PFU, false, S>(s, p, err_out);
                 return;
             }
         }
@@ -1007,6 +1117,10 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
 {
     if (pre != 0 && !(recompute_instantiated(pre, steps) && coarse && !Fc)) {
         fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 1+1, 2+2 and 3+3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
+        return;
+    }
+    if (pre != 0 && D_out) {
+        fail(MG_ERR_ARG, "jacobi_stream: the recomputing `1` node forms the error norm only, it stores no residual");
         return;
     }
     if (steps < 1 || steps > MAX_S) {
@@ -1070,6 +1184,8 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         default: launch_steps<4>(s, p, err_out); break;
     }
 }
+
+#endif  // MG_STREAM_KERNEL_ONLY
 
 }  // namespace MG_REAL_NS
 }  // namespace k
