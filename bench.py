@@ -234,6 +234,7 @@ def time_cycle(mg, plan, steps, warmup, profile_min_N=None):
     file needs no per-step host sync), bracketed by synchronisation; optional live hipEvent pairs."""
     first = plan.execute()   # (pool, tables, code objects)
     assert first["status"] == 0, first
+    time_cycle.first_ms = first["device_ms"]
     # the W untimed steps run exactly like the timed ones -- enqueued back to back -- so the clocks are where a
     # sustained run holds them when the timed region starts (measured: the first 20 windows after an idle gap take
     # 0.80-0.82 ms, from the ~40th on 0.735)
@@ -313,6 +314,51 @@ def main():
     # the W-cycle's algorithmic bytes are the per-level term weighted by the level's visits
     algo_bytes = sum(v * ((8 + 24 * nu + 24 + 8 + 16 + 24 * nu) * a * a + 16.0 * b * b) for v, a, b in zip(visits, sizes[:-1], sizes[1:]))
 
+    # The strong-scaling bases run FIRST: besides being legs of the line they are ~0.3 s of sustained load, after which
+    # the headline leg -- W untimed and K timed windows exactly as passed -- starts at the clocks a sustained run holds
+    # (after an idle gap the device needs ~40 windows to get there: profiles/r03_warmup.txt; `clock_state` in the line
+    # says what preceded the timed region and how the first and the last window of this leg compare).
+    pre_legs, windows_before = {}, 0
+    # ---- strong-scaling base: the V-cycle of BASELINE.json configs[3] (N = 16384^2) on this one GPU ----
+    if not args.no_strong and args.cycle == "V" and N != STRONG_N:
+        try:
+            scyc = os.path.join(tmp, f"Vcycle_{STRONG_N}.txt")
+            mg.write_vcycle_file(scyc, STRONG_N, args.n_min, nu, 1e-7)
+            ssizes = level_sizes(STRONG_N, args.n_min)
+            slups = sum(2 * nu * s * s for s in ssizes[:-1])
+            splan = mg.CyclePlan(scyc, fused=True, report=False, error=False, mixed=args.mixed)
+            sms, sr, _ = time_cycle(mg, splan, args.steps, max(1, args.warmup))
+            windows_before += 1 + max(1, args.warmup) + args.steps
+            scb = vcycle_compulsory_bytes(ssizes) * (0.5 if args.mixed else 1.0)
+            pre_legs["strong_scaling"] = {"N": STRONG_N, "n_gpus": 1, "ms_per_step": round(sms, 4), "value": round(slups / (sms * 1e-3) / 1e6, 1),
+                                     "unit": "MLUPS", "steps": args.steps, "scaling": "strong",
+                                     "workload": f"V({nu},{nu})-cycle N={STRONG_N}^2 fp64 (BASELINE.json configs[3]), one GPU: the base of the strong-scaling curve",
+                                     "cycle_frac_of_hbm_peak": round(scb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            splan.close()
+            mg.lib().mg_pool_trim()
+        except mg.MGError as exc:
+            pre_legs["strong_scaling"] = {"error": str(exc)}
+
+    # ---- the same one level up: N = 32768^2 fp64 (few windows: 10 ms each) ----
+    if not args.no_strong and not args.no_large and args.cycle == "V" and not args.mixed and N != LARGE_N:
+        try:
+            lcyc = os.path.join(tmp, f"Vcycle_{LARGE_N}.txt")
+            mg.write_vcycle_file(lcyc, LARGE_N, args.n_min, nu, 1e-7)
+            lsizes = level_sizes(LARGE_N, args.n_min)
+            llups = sum(2 * nu * s * s for s in lsizes[:-1])
+            lplan = mg.CyclePlan(lcyc, fused=True, report=False, error=False)
+            lsteps = min(args.steps, 10)
+            lms, _, _ = time_cycle(mg, lplan, lsteps, min(max(1, args.warmup), 10))
+            windows_before += 1 + min(max(1, args.warmup), 10) + lsteps
+            pre_legs["strong_scaling_32768"] = {"N": LARGE_N, "n_gpus": 1, "ms_per_step": round(lms, 4), "value": round(llups / (lms * 1e-3) / 1e6, 1),
+                                           "unit": "MLUPS", "steps": lsteps, "scaling": "strong",
+                                           "workload": f"V({nu},{nu})-cycle N={LARGE_N}^2 fp64, one GPU: base of a second strong-scaling curve",
+                                           "cycle_frac_of_hbm_peak": round(vcycle_compulsory_bytes(lsizes) / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            lplan.close()
+            mg.lib().mg_pool_trim()
+        except mg.MGError as exc:
+            pre_legs["strong_scaling_32768"] = {"error": str(exc)}
+
     refine = max(1, args.refine) if args.mixed else 1
     plan = mg.CyclePlan(cyc, fused=(args.mode != "unfused"), graph=(args.mode == "graph"), report=False, error=False,
                         mixed=args.mixed, refinement=refine)
@@ -371,7 +417,12 @@ def main():
         "mg_error": plan.analytic_error(r),
         "roofline": roof,
         "kernels": kernels[:8],
+        # what the device had been doing when the timed region started (windows of all legs, this one's first run and its
+        # W untimed ones) and the device time of this leg's first and last window
+        "clock_state": {"windows_before_timed": windows_before + 1 + max(args.warmup, 2 if args.mode == "graph" else 0),
+                        "first_window_ms": round(time_cycle.first_ms, 4), "last_window_ms": round(dev_ms, 4)},
     }
+    out.update(pre_legs)
     if algo_bytes:
         cb = vcycle_compulsory_bytes(sizes, visits=visits) * elem * refine
         if refine > 1:   # per joint: fp64 iterate + fp64 source read, fp32 source written; fp32 correction read, fp64 iterate read + written
@@ -382,44 +433,6 @@ def main():
                                  "algorithmic_equiv": {"bytes": algo_bytes, "GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1)}}
     plan.close()
     mg.lib().mg_pool_trim()
-
-    # ---- strong-scaling base: the V-cycle of BASELINE.json configs[3] (N = 16384^2) on this one GPU ----
-    if not args.no_strong and args.cycle == "V" and N != STRONG_N:
-        try:
-            scyc = os.path.join(tmp, f"Vcycle_{STRONG_N}.txt")
-            mg.write_vcycle_file(scyc, STRONG_N, args.n_min, nu, 1e-7)
-            ssizes = level_sizes(STRONG_N, args.n_min)
-            slups = sum(2 * nu * s * s for s in ssizes[:-1])
-            splan = mg.CyclePlan(scyc, fused=True, report=False, error=False, mixed=args.mixed)
-            sms, sr, _ = time_cycle(mg, splan, args.steps, max(1, args.warmup))
-            scb = vcycle_compulsory_bytes(ssizes) * elem
-            out["strong_scaling"] = {"N": STRONG_N, "n_gpus": 1, "ms_per_step": round(sms, 4), "value": round(slups / (sms * 1e-3) / 1e6, 1),
-                                     "unit": "MLUPS", "steps": args.steps, "scaling": "strong",
-                                     "workload": f"V({nu},{nu})-cycle N={STRONG_N}^2 fp64 (BASELINE.json configs[3]), one GPU: the base of the strong-scaling curve",
-                                     "cycle_frac_of_hbm_peak": round(scb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            splan.close()
-            mg.lib().mg_pool_trim()
-        except mg.MGError as exc:
-            out["strong_scaling"] = {"error": str(exc)}
-
-    # ---- the same one level up: N = 32768^2 fp64 (few windows: 10 ms each) ----
-    if not args.no_strong and not args.no_large and args.cycle == "V" and not args.mixed and N != LARGE_N:
-        try:
-            lcyc = os.path.join(tmp, f"Vcycle_{LARGE_N}.txt")
-            mg.write_vcycle_file(lcyc, LARGE_N, args.n_min, nu, 1e-7)
-            lsizes = level_sizes(LARGE_N, args.n_min)
-            llups = sum(2 * nu * s * s for s in lsizes[:-1])
-            lplan = mg.CyclePlan(lcyc, fused=True, report=False, error=False)
-            lsteps = min(args.steps, 10)
-            lms, _, _ = time_cycle(mg, lplan, lsteps, min(max(1, args.warmup), 10))
-            out["strong_scaling_32768"] = {"N": LARGE_N, "n_gpus": 1, "ms_per_step": round(lms, 4), "value": round(llups / (lms * 1e-3) / 1e6, 1),
-                                           "unit": "MLUPS", "steps": lsteps, "scaling": "strong",
-                                           "workload": f"V({nu},{nu})-cycle N={LARGE_N}^2 fp64, one GPU: base of a second strong-scaling curve",
-                                           "cycle_frac_of_hbm_peak": round(vcycle_compulsory_bytes(lsizes) / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            lplan.close()
-            mg.lib().mg_pool_trim()
-        except mg.MGError as exc:
-            out["strong_scaling_32768"] = {"error": str(exc)}
 
     # north_star's own yardstick, measured beside the cycle: ONE fine-level Jacobi sweep per launch (doSmoothing with
     # step = 1, 24 B per point: compulsory == algorithmic here) -- the one-row-per-block pair kernel that the engine

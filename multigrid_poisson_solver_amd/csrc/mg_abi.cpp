@@ -274,6 +274,10 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
     const double inv = 1.0 / dx2;
     const size_t n = (size_t)N * N;
 
+    if (step <= 0 && c.trace) {
+        c.trace_failed = true;
+        return;
+    }
     if (step <= 0) {  // no sweep: U_out = U_in
         if (U_in) (void)hipMemcpyAsync(U_out, U_in, n * sizeof(double), hipMemcpyDeviceToDevice, s);
         else (void)hipMemsetAsync(U_out, 0, n * sizeof(double), s);
@@ -283,6 +287,43 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
     }
 
     const bool stream = c.smoother != SMOOTHER_SIMPLE && k::stream_supported(N);
+    if (c.trace) {
+        // the cycle driver's dataflow trace: describe the launch instead of enqueueing it.  Only a node that is ONE fused
+        // launch of the streaming or the tile kernel can be batched with its peers
+        const int smax1 = stream ? k::stream_max_steps() : 1;
+        if (!stream || step > smax1 || D_out || !error_dev || (fu.coarse && fu.Fc)) {
+            c.trace_failed = true;
+            return;
+        }
+        NodeOp op;
+        // (levels between the batched schedule's coarse tail and the tile kernel's usual range: the tile kernel as well)
+        const bool as_tile = c.smoother == SMOOTHER_STREAM && fu.pre == 0 && (k::tile_wanted(N) || (N >= 16 && N <= k::TAIL_MAX_N)) && step <= k::tile_max_steps();
+        op.kind = as_tile ? 1 : 0;
+        op.N = N;
+        op.L = L;
+        op.src = U_in;
+        op.F = F;
+        op.dst = U_out;
+        op.take = step;
+        op.err = error_dev;
+        op.d_sign = d_sign;
+        op.coarse = fu.coarse;
+        op.Nc = fu.Nc;
+        op.Fc = fu.Fc;
+        op.M = fu.M;
+        op.pre = fu.pre;
+        op.no_out = fu.no_out;
+        const bool pro = fu.coarse != nullptr, rst = fu.Fc != nullptr;
+        char pre_tag[8] = "";
+        if (fu.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", fu.pre);
+        snprintf(op.name, sizeof op.name, "%s<%d%s%s%s%s%s>", as_tile ? "jacobi_tile" : "jacobi_stream", step, (U_in || fu.pre) ? "" : ",zero",
+                 pro ? ",prolong" : "", rst ? ",res,restrict" : "", fu.no_out ? ",noU" : "", pre_tag);
+        op.bytes = (double)n * (24.0 * (step + fu.pre) + ((U_in || fu.pre) ? 0.0 : 8.0) + (rst ? 24.0 : 0.0));
+        if (rst) op.bytes += 8.0 * n + 8.0 * fu.M * fu.M;
+        if (pro) op.bytes += 16.0 * n + 8.0 * fu.Nc * fu.Nc;
+        c.trace->push_back(op);
+        return;
+    }
     // sweeps per launch: the streaming kernel advances up to stream_max_steps() time
     // levels per pass over HBM, the simple kernel one.  The launch count is made odd so
     // that, ping-ponging between U_out and one partner buffer, the last launch lands in
@@ -370,6 +411,8 @@ void smooth_pp(int N, double L, const double *U_in, double *U_out, double *F, in
 int recompute_min_n()
 {
     static const int min_n = [] { const char *e = getenv("MG_RECOMPUTE_MIN_N"); return e ? atoi(e) : 4096; }();  // (measured: 2048 loses 4 us per level, 4096 gains 35, 8192 gains 130)
+    // a batched schedule carries 2^l instances of level l in one launch: what decides there is the launch, not the grid
+    if (ctx().recompute_min_override > 0) return ctx().recompute_min_override;
     return min_n;
 }
 
@@ -413,6 +456,27 @@ void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double
     fu.pt = &prolong_table(Nc, N);
     fu.pre = pre;
     smooth_pp(N, L, nullptr, U_out, F, step, error_dev, nullptr, +1, fu);
+}
+
+// One launch for n recorded instances of the same fused node (the independent visits of a level, mg_cycle.cpp); the
+// name carries the batch size, the algorithmic bytes are those of all instances.
+void replay_node(const NodeOp &op, const NodeBatch *batch)
+{
+    Context &c = ctx();
+    const double dx2 = spacing_sq(op.N, op.L), inv = 1.0 / dx2;
+    const ProlongTable *pt = op.coarse ? &prolong_table(op.Nc, op.N) : nullptr;
+    const RestrictTable *rt = op.Fc ? &restrict_table(op.N, op.M) : nullptr;
+    const int nb = batch ? batch->n : 1;
+    char name[64];
+    if (nb > 1) snprintf(name, sizeof name, "%s x%d", op.name, nb);
+    else snprintf(name, sizeof name, "%s", op.name);
+    ProfScope ps(name, op.N, op.bytes * nb);
+    if (op.kind == 1)
+        k::jacobi_tile(c.stream, op.N, dx2, inv, op.src, op.F, op.dst, op.take, op.err, op.d_sign, op.coarse, op.Nc, pt, op.Fc, op.M, rt, op.no_out,
+                       nullptr, nullptr, nullptr, batch);
+    else
+        k::jacobi_stream(c.stream, op.N, dx2, inv, op.src, op.F, op.dst, op.take, op.err, nullptr, op.d_sign, op.coarse, op.Nc, pt, op.Fc, op.M, rt,
+                         nullptr, nullptr, nullptr, op.pre, op.no_out, batch);
 }
 
 }  // namespace mg

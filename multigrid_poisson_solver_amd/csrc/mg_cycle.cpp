@@ -13,7 +13,9 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
+#include <map>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -35,11 +37,9 @@ struct LevelNode {  // src/linkedlist.h:4-30
     // > 0: U holds nothing yet -- it is `pending_pre` Jacobi sweeps from zero on this F, which the fused `-1` node did
     // not store (smooth_restrict_no_out); the fused `1` node recomputes it in flight, anyone else calls ensure_U first
     int pending_pre = 0;
-    // independent sub-cycles (mg_cycle_plan::fork): how many `-1` nodes have left this level since it was pushed, and the
-    // event after which its F is complete (recorded behind the restriction that produced it)
+    // how many `-1` nodes have left this level since it was pushed (the dataflow trace gives every re-descent arrays of
+    // its own: mg_cycle_plan::sched)
     int descents = 0;
-    hipEvent_t f_ready = nullptr;
-    hipStream_t f_stream = nullptr;  // where f_ready was recorded (a wait on the same stream is implied by stream order)
 };
 
 class LevelList {
@@ -160,22 +160,31 @@ struct mg_cycle_plan {
     int warm_runs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_status = 0;
-    // ---- independent sub-cycles on their own streams ----------------------------------------------------------------
+    // ---- batched breadth-first schedule ------------------------------------------------------------------------------
     // The reference zeroes a level's U before every pre-smoothing except the restart case (src/MG_solver_CPU.cpp:252-257),
     // so a `-1` node reads nothing but its level's F.  When a cycle file comes back up to a level and descends from it
     // AGAIN (the second half of every W-cycle visit: ... 1 -1 ...), that second sub-cycle depends on the level's F alone
     // -- not on anything the first sub-cycle produced (whose result the zero fill discards; only its smoothing errors
-    // are ever looked at).  The driver therefore starts it on another stream, behind the event of that F, and lets the
-    // first sub-cycle finish on the stream it was enqueued on.  Every node still runs, with the same inputs, the same
-    // launches and the same bits; records and report are assembled in file order as always.  What changes is that
-    // kernels of a few workgroups each (one workgroup for a coarse-tail launch) no longer queue behind one another.
-    bool fork = false;               // the file has such re-descents above the coarse tail and every node in it is fork-safe
-    int fork_max_N = 0;              // re-descents from levels up to this size fork (larger levels fill the GPU on their own)
-    std::vector<hipStream_t> side;   // stream pool of the forked sub-cycles (round robin)
-    std::vector<hipEvent_t> events;  // F-ready and join events, reused window after window
-    size_t events_used = 0;
-    int *gs_slots = nullptr;         // [2 * launches] exact-solver state per coarse-tail launch (concurrent launches must not share one)
-    int tail_launches = 0;
+    // are ever looked at).  So the node program of a fixed-step file is a DATAFLOW GRAPH in which all 2^l visits of level
+    // l of a W-cycle are independent of one another.  build_schedule() traces the file ONCE with the interpreter below
+    // (every fused node described instead of launched, every visit on arrays of its own), orders the nodes by their depth
+    // in that graph and merges the nodes of one depth and one shape into ONE launch with a batch dimension: a W-cycle
+    // becomes as many launches as a V-cycle (2 per level + one coarse-tail launch of 64 workgroups at 8192^2).  Every
+    // node still runs, on the same inputs, with the same expressions: same bits; records and report stay in file order.
+    std::vector<NodeOp> ops;             // the traced nodes, file order
+    std::vector<k::TailArgs> tails;      // coarse-tail slices among them (NodeOp::tail)
+    struct Group {
+        int depth = 0, first = 0;        // dataflow depth, first op (file order)
+        std::vector<int> members;        // ops of this launch
+        size_t items_at = 0;             // where its instance table starts in sched_items (bytes)
+        std::vector<double *> errs;      // per instance: device slot of its smoothing error
+    };
+    std::vector<Group> sched;
+    void *sched_items = nullptr;         // device: the instance tables of all groups
+    bool sched_ready = false, sched_tried = false;
+    int sched_max_batch = 0;
+    int *gs_slots = nullptr;             // [2 * tails] exact-solver state per coarse-tail instance
+    int last_tail = -1;                  // the tail whose state mg_lastExactSolverIterations() reports (last in file order)
 };
 
 namespace mg {
@@ -306,10 +315,10 @@ struct Exec {
     int status = 0;
     bool capturing = false;
     bool widened = false;  // mixed mode: the last node stored its result in fp64 (plan->U64) itself
-    bool forking = false;  // this pass starts re-descents on side streams (plan->fork)
-    hipStream_t home = nullptr;      // the engine's stream: where the window starts and, after the join, ends
-    std::vector<char> side_used;
-    size_t next_side = 0;
+    // dataflow trace (build_schedule): nodes are described, not launched; every visit of a level gets arrays of its own;
+    // a node that is not one fused launch (restart, trigger mode, a stand-alone exact solve, 0 steps ...) ends the attempt
+    bool tracing = false;
+    bool untraceable = false;
 
     bool next(double *v)
     {
@@ -380,66 +389,6 @@ void ensure_U(mg_cycle_plan *p, LevelNode *lv)
     lv->pending_pre = 0;
 }
 
-hipEvent_t next_event(mg_cycle_plan *p)
-{
-    if (p->events_used == p->events.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        p->events.push_back(e);
-    }
-    return p->events[p->events_used++];
-}
-
-// A re-descent from lv (zero start: it reads lv->F and nothing else) begins on the next side stream, behind the event of
-// that F.  The sub-cycle enqueued before it may still be running: it keeps the level's old U and D (they return to the pool
-// when the window ends: Pool::park), this one gets fresh ones.  Everything that follows in the file -- this sub-cycle and
-// the way up from it -- stays on the new stream; the old stream only has to finish what it holds before the window ends.
-void fork_branch(Exec &x, LevelNode *lv)
-{
-    mg_cycle_plan *p = x.p;
-    const size_t k = x.next_side++ % p->side.size();
-    hipStream_t t = p->side[k];
-    if (lv->f_stream != t) (void)hipStreamWaitEvent(t, lv->f_ready, 0);
-    x.c.stream = t;
-    x.side_used[k] = 1;
-    const size_t bytes = (size_t)lv->N * lv->N * sizeof(double);
-    p->pool.put(lv->U);
-    p->pool.put(lv->D);
-    lv->U = (double *)p->pool.get(bytes);
-    lv->D = (double *)p->pool.get(bytes);
-    lv->pending_pre = 0;
-}
-
-// the window ends on the engine's stream, behind everything any side stream still holds
-void join_branches(Exec &x)
-{
-    if (!x.forking) return;
-    mg_cycle_plan *p = x.p;
-    hipStream_t cur = x.c.stream;
-    for (size_t k = 0; k < p->side.size(); ++k) {
-        if (!x.side_used[k] || p->side[k] == cur) continue;
-        hipEvent_t e = next_event(p);
-        if (!e) { x.status = 16; continue; }
-        (void)hipEventRecord(e, p->side[k]);
-        (void)hipStreamWaitEvent(cur, e, 0);
-    }
-    if (cur != x.home) {
-        hipEvent_t e = next_event(p);
-        if (!e) x.status = 16;
-        else {
-            (void)hipEventRecord(e, cur);
-            (void)hipStreamWaitEvent(x.home, e, 0);
-        }
-    }
-    x.c.stream = x.home;
-    // mg_lastExactSolverIterations(): the state of the LAST coarse-tail launch of the file (each launch had its own slot)
-    if (p->tail_launches > 0)
-        (void)hipMemcpyAsync(x.c.gs_state, p->gs_slots + 2 * (p->tail_launches - 1), 2 * sizeof(int), hipMemcpyDeviceToDevice, x.home);
-}
-
 // fixed-step smoothing of the last level, result in lv->U.  zero_start: the driver's
 // memset(U,0) (:256) is folded into the first sweep.  want_D: also produce -residual in
 // lv->D (getResidual :268 and the sign flip :277-280 folded into the last sweep).
@@ -488,6 +437,12 @@ bool try_tail(Exec &x)
     LevelList &cycle = *p->levels;
     if (p->con_N != 1) return false;
     LevelNode *top = cycle.last();
+    // A batched schedule starts its coarse tail one level further down: a W-cycle's 64 slices from N = 64 are 64 workgroups
+    // of 130 us (8 solves, 28 smoothing nodes each), its 128 slices from N = 32 are half as long on twice as many CUs, and the
+    // 128 visits of level 64 are two batched launches of the register-tile kernel (measured, W(3,3) at 8192^2: tail from
+    // 64 / 32 / 16: 1.088 / 1.045 / 1.053 ms)
+    static const int batch_tail_n = [] { const char *e = getenv("MG_BATCH_TAIL_N"); return e ? atoi(e) : 32; }();
+    if (x.tracing && top->N > batch_tail_n) return false;
 
     k::TailArgs a;
     int node_level[k::TAIL_MAX_NODES];
@@ -495,6 +450,9 @@ bool try_tail(Exec &x)
     if (!scan_tail(p->tokens, &tok, p->sizes, x.at, p->con_step, top->N, p->L, &a, node_level)) return false;
     const int n_nodes = a.n_nodes;
     if (p->records.size() + (size_t)n_nodes > p->err_cap) return false;  // (cannot happen: err_cap counts every node token)
+    // the slice's records are consecutive: its error slots count from the first of them (so that every instance of a
+    // batched launch can run the same node program on an error array of its own)
+    const int rec0 = (int)p->records.size();
     // records + report, in the order the per-node interpreter would emit them
     const char *down = "             *\n             |\n Restriction |\n             |\n             *\n";
     const char *up = "             *\n             |\nProlongation |\n             |\n             *\n";
@@ -502,8 +460,9 @@ bool try_tail(Exec &x)
         k::TailNode &nd = a.nodes[i];
         const int N = a.N[node_level[i]];
         if (nd.type == -1) {
-            nd.err_slot = add_record(p, -1, N, nd.steps);
-            report_smoothing(p, nd.err_slot);
+            const int rec = add_record(p, -1, N, nd.steps);
+            nd.err_slot = rec - rec0;
+            report_smoothing(p, rec);
             report_text(p, down);
         } else if (nd.type == 0) {
             add_record(p, 0, N, 0);
@@ -516,16 +475,17 @@ bool try_tail(Exec &x)
                 report_text(p, t.s.c_str());
             }
         } else {
-            nd.err_slot = add_record(p, 1, N, nd.steps);
+            const int rec = add_record(p, 1, N, nd.steps);
+            nd.err_slot = rec - rec0;
             report_text(p, up);
-            report_smoothing(p, nd.err_slot);
+            report_smoothing(p, rec);
         }
     }
     if (p->flags & MG_CYCLE_MIXED) {
         k::TailArgsF f = tail_args_f32(a);
         f.F_top = (const float *)top->F;
         f.U_top = (float *)top->U;
-        f.err_dev = p->err_dev;
+        f.err_dev = p->err_dev + rec0;
         f.gs_state = x.c.gs_state;
         ProfScope ps("coarse_tail_f32", top->N, 0.0);
         k::tail_launch_f32(x.c.stream, f);
@@ -534,8 +494,20 @@ bool try_tail(Exec &x)
     }
     a.F_top = top->F;
     a.U_top = top->U;
-    a.err_dev = p->err_dev;
-    a.gs_state = x.forking ? p->gs_slots + 2 * p->tail_launches++ : x.c.gs_state;
+    a.err_dev = p->err_dev + rec0;
+    a.gs_state = x.c.gs_state;
+    if (x.tracing) {  // described, not launched (its exact-solver state slot is assigned when the schedule is built)
+        NodeOp op;
+        op.kind = 2;
+        op.N = top->N;
+        op.F = top->F;
+        op.dst = top->U;
+        op.tail = (int)p->tails.size();
+        p->tails.push_back(a);
+        p->ops.push_back(op);
+        x.tok = tok;
+        return true;
+    }
     // diagnostics: MG_TAIL_TRACE=1 prints the in-kernel timeline of the first traced launches
     static const bool trace_on = getenv("MG_TAIL_TRACE") != nullptr;
     static int traced = 0;
@@ -582,15 +554,16 @@ void run_nodes(Exec &x)
     const bool fused = (p->flags & MG_CYCLE_FUSED) != 0;
     const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0;
     x.c.defer_norms = true;
-    x.forking = p->fork && fused && !mixed;
-    x.home = x.c.stream;
-    if (x.forking) {
-        x.side_used.assign(p->side.size(), 0);
-        p->events_used = 0;
-        p->tail_launches = 0;
-        x.c.norms_at_window_end = true;   // a mid-window reduction could run ahead of nodes on other streams
-        p->pool.park(true);               // no block changes hands between streams inside the window
-    }
+    // what a node must be for the dataflow trace: ONE fused launch (smooth_pp records it) -- checked here wherever the
+    // entry point below would otherwise fall back to operator-by-operator launches
+    auto fusable_down = [&](int N, int M, int step) {
+        const RestrictTable &rt = restrict_table(N, M);
+        return step >= 1 && step <= k::stream_max_steps() && x.c.smoother != SMOOTHER_SIMPLE && k::stream_fusable(N) && rt.lo && rt.fusable;
+    };
+    auto fusable_up = [&](int Nc, int N, int step) {
+        const ProlongTable &pt = prolong_table(Nc, N);
+        return step >= 1 && step <= k::stream_max_steps() && x.c.smoother != SMOOTHER_SIMPLE && k::stream_fusable(N) && pt.owner_row && pt.fusable;
+    };
 
     for (;;) {
         int node;
@@ -610,6 +583,7 @@ void run_nodes(Exec &x)
             }
             if (step == 0) continue;  // :241-243, :296-299 (FMG stub)
             if (next_N < 3) { x.status = 7; break; }
+            if (x.tracing && (step < 1 || !fused || mixed)) { x.untraceable = true; break; }
 
             LevelNode *lv = cycle.last();
             const bool keep = (cycle.Get_init() == 0 && cycle.Is_firstNode());  // :209-214, :252-257
@@ -651,8 +625,19 @@ void run_nodes(Exec &x)
             } else if (fused) {
                 // smoothing (:259), residual (:268), sign flip (:277-280) and restriction (:287)
                 // in one pass; the zero fill of U (:256) is folded into the first sweep
-                // a second descent from this level reads its F alone: on its own stream (see mg_cycle_plan::fork)
-                if (x.forking && !keep && lv->descents > 0 && lv->f_ready && lv->N <= p->fork_max_N) fork_branch(x, lv);
+                if (x.tracing) {
+                    if (keep || !fusable_down(lv->N, next_N, step)) { x.untraceable = true; break; }
+                    if (lv->descents > 0) {
+                        // a second descent from this level reads its F alone (zero start): an independent task of the
+                        // dataflow -- on arrays of its own, so that it can run beside the first one
+                        const size_t bytes = (size_t)lv->N * lv->N * sizeof(double);
+                        p->pool.put(lv->U);
+                        p->pool.put(lv->D);
+                        lv->U = (double *)p->pool.get(bytes);
+                        lv->D = (double *)p->pool.get(bytes);
+                        lv->pending_pre = 0;
+                    }
+                }
                 lv->descents++;
                 rec = add_record(p, -1, lv->N, step);
                 report_smoothing(p, rec);
@@ -674,14 +659,6 @@ void run_nodes(Exec &x)
                     p->pool.put(tmp);
                 }
                 report_text(p, "             *\n             |\n Restriction |\n             |\n             *\n");
-                if (x.forking && next_N > k::TAIL_MAX_N && next_N <= p->fork_max_N) {
-                    // the new level's F is complete behind this launch: what a later re-descent from it waits for
-                    hipEvent_t e = next_event(p);
-                    if (e && hipEventRecord(e, x.c.stream) == hipSuccess) {
-                        cycle.last()->f_ready = e;
-                        cycle.last()->f_stream = x.c.stream;
-                    }
-                }
                 try_tail(x);  // levels N <= 64: the rest of this descent and its way back up in one launch
                 continue;
             } else {
@@ -698,6 +675,7 @@ void run_nodes(Exec &x)
             int option;
             if (!x.next(&tol) || !x.next_int(&option)) { x.status = 3; break; }
             LevelNode *lv = cycle.last();
+            if (x.tracing) { x.untraceable = true; break; }   // a stand-alone exact solve (those of a coarse tail never get here)
             if (mixed) { x.status = 15; break; }  // fp32 coarse solves exist inside the tail kernel only
             if (x.capturing && lv->N > k::gs_single_workgroup_max_n()) { x.status = 8; break; }
             mg_doExactSolver(lv->N, p->L, lv->U, lv->F, tol, option);
@@ -754,6 +732,11 @@ void run_nodes(Exec &x)
                 report_text(p, arrow);
                 report_smoothing(p, rec);
                 continue;
+            }
+            if (x.tracing && (coarse->pending_pre > 0 || !fused || !fusable_up(coarse->N, fine->N, step) ||
+                              (fine->pending_pre > 0 && !recompute_available(coarse->N, fine->N, fine->pending_pre, step)))) {
+                x.untraceable = true;
+                break;
             }
             ensure_U(p, coarse);
             if (fused && step > 0 && fine->pending_pre > 0 && recompute_available(coarse->N, fine->N, fine->pending_pre, step)) {
@@ -813,16 +796,12 @@ void run_nodes(Exec &x)
     // the last level never does): materialise it HERE, as part of the node program, so that a captured graph replays it
     // too and the work lies inside the timed window of every run.  fp32 fields have no such launch: an explicit status.
     if (x.status == 0 && cycle.last() && cycle.last()->pending_pre > 0) {
-        if (mixed) x.status = 15;
+        if (x.tracing) x.untraceable = true;
+        else if (mixed) x.status = 15;
         else ensure_U(p, cycle.last());
     }
-    join_branches(x);
     flush_norms();  // the window's smoothing errors: one reduction launch
     x.c.defer_norms = false;
-    if (x.forking) {
-        x.c.norms_at_window_end = false;
-        p->pool.park(false);
-    }
 }
 
 // reset the level stack to the state right after getSource (:149-153)
@@ -832,62 +811,214 @@ void reset_levels(mg_cycle_plan *p)
     // keep the finest level (its F never changes); drop anything a broken file left over
     while (cycle.depth() > 1) cycle.Remove_back();
     cycle.Set_init(1);
-    if (cycle.first()) {
-        cycle.first()->descents = 0;
-        cycle.first()->f_ready = nullptr;
-    }
-    // blocks the previous window set aside: its streams were joined on the engine's stream, which everything of this
-    // window is ordered behind
-    p->pool.release_parked();
+    if (cycle.first()) cycle.first()->descents = 0;
     p->records.clear();
     p->report_items.clear();
 }
 
-// Does the file descend again from a level it has come back up to (mg_cycle_plan::fork), above the coarse tail and at most
-// max_n wide, and is every node fork-safe (exact solves only inside coarse-tail launches, which get a state slot each)?
-void plan_forks(mg_cycle_plan *p)
+// ---------------------------------------------------------------------------
+// The batched breadth-first schedule (mg_cycle_plan::sched)
+// ---------------------------------------------------------------------------
+bool same_shape(const mg_cycle_plan *p, const NodeOp &a, const NodeOp &b)
 {
-    static const bool on = [] { const char *e = getenv("MG_CYCLE_FORK"); return !e || atoi(e) != 0; }();
-    static const int max_n = [] { const char *e = getenv("MG_FORK_MAX_N"); return e ? atoi(e) : 4096; }();
-    // (measured, W(3,3) at 8192, default 4 hardware queues: 8 / 16 / 32 streams 4.84 / 4.30 / 4.12 ms with forks up to level 4096,
-    // 5.23 / 4.56 / 4.34 with forks up to 1024; serial 10.13; GPU_MAX_HW_QUEUES=8 or 16 is SLOWER: 6.3-8.1 ms)
-    static const int n_streams = [] { const char *e = getenv("MG_FORK_STREAMS"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
-    if (!on || getenv("MG_NO_TAIL")) return;
-    std::vector<int> descents(1, 0);
-    size_t at = 0, tok = 0;
-    bool points = false;
-    while (tok < p->tokens.size()) {
-        const int node = (int)p->tokens[tok++];
-        if (node == 2) break;
-        if (node == -1) {
-            if (at + 1 >= p->sizes.size()) break;  // (the run ends with status 4)
-            const int N = p->sizes[at];
-            if (descents.back() > 0 && N > k::TAIL_MAX_N && N <= max_n) points = true;
-            descents.back()++;
-            descents.push_back(0);
-            ++at;
-        } else if (node == 0) {
-            tok += 2;
-            if (p->sizes[at] > k::TAIL_MAX_N) return;  // a stand-alone exact solve: shared solver state
-        } else if (node == 1) {
-            if (descents.size() < 2) break;
-            descents.pop_back();
-            --at;
+    if (a.kind != b.kind || a.N != b.N) return false;
+    if (a.kind == 2) {
+        const k::TailArgs &x = p->tails[(size_t)a.tail], &y = p->tails[(size_t)b.tail];
+        if (x.n_levels != y.n_levels || x.n_nodes != y.n_nodes) return false;
+        for (int l = 0; l < x.n_levels; ++l)
+            if (x.N[l] != y.N[l]) return false;
+        for (int i = 0; i < x.n_nodes; ++i) {
+            const k::TailNode &m = x.nodes[i], &n = y.nodes[i];
+            if (m.type != n.type || m.steps != n.steps || m.err_slot != n.err_slot || m.tol != n.tol) return false;
+        }
+        return true;
+    }
+    return a.take == b.take && a.pre == b.pre && a.no_out == b.no_out && a.d_sign == b.d_sign && (a.src == nullptr) == (b.src == nullptr) &&
+           (a.coarse == nullptr) == (b.coarse == nullptr) && (a.Fc == nullptr) == (b.Fc == nullptr) && a.Nc == b.Nc && a.M == b.M && a.L == b.L;
+}
+
+void drop_schedule(mg_cycle_plan *p)
+{
+    p->sched.clear();
+    p->ops.clear();
+    p->tails.clear();
+    p->sched_ready = false;
+    if (p->sched_items) (void)hipFree(p->sched_items);
+    p->sched_items = nullptr;
+    if (p->gs_slots) p->pool.put(p->gs_slots);
+    p->gs_slots = nullptr;
+    p->last_tail = -1;
+    p->pool.park(false);
+    p->pool.release_parked();
+}
+
+// Trace the file once, build the dataflow depths, merge equal nodes of equal depth.  On success the plan keeps every array
+// the trace handed out (one set per visit: 6 n_0 doubles for a W-cycle, 3 GiB at 8192^2) and mg_cycle_enqueue replays
+// p->sched; otherwise everything is returned and the interpreter runs the file node by node as before.
+void build_schedule(mg_cycle_plan *p)
+{
+    static const bool on = [] { const char *e = getenv("MG_CYCLE_BATCH"); return !e || atoi(e) != 0; }();
+    p->sched_tried = true;
+    const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0, fused = (p->flags & MG_CYCLE_FUSED) != 0;
+    if (!on || !fused || mixed || p->con_N != 1 || p->con_step < 1 || getenv("MG_NO_TAIL")) return;
+    // worth it only where the file descends again from a level it has come back up to
+    {
+        std::vector<int> descents(1, 0);
+        bool points = false;
+        for (size_t tok = 0; tok < p->tokens.size() && !points;) {
+            const int node = (int)p->tokens[tok++];
+            if (node == 2) break;
+            if (node == -1) {
+                if (descents.back() > 0) points = true;
+                descents.back()++;
+                descents.push_back(0);
+            } else if (node == 0) {
+                tok += 2;
+            } else if (node == 1) {
+                if (descents.size() < 2) break;
+                descents.pop_back();
+            }
+        }
+        if (!points) return;
+    }
+    Context &c = ctx();
+    reset_levels(p);
+    c.active_pool = &p->pool;
+    p->pool.park(true);   // nothing the trace returns is handed out again: every visit keeps arrays of its own
+    c.trace = &p->ops;
+    c.trace_failed = false;
+    // (measured, W(3,3) at 8192^2: the recomputing pair from 4096 / 2048 / 1024 / 512 on: 1.194 / 1.158 / 1.143 / 1.158 ms)
+    static const int batch_recompute_min = [] { const char *e = getenv("MG_BATCH_RECOMPUTE_MIN_N"); return e ? atoi(e) : 1024; }();
+    if (!getenv("MG_RECOMPUTE_MIN_N")) c.recompute_min_override = batch_recompute_min;
+    Exec x{p, c};
+    x.tracing = true;
+    run_nodes(x);
+    c.recompute_min_override = 0;
+    c.trace = nullptr;
+    c.active_pool = nullptr;
+    const bool ok = x.status == 0 && !x.untraceable && !c.trace_failed && !c.last_error && !p->ops.empty();
+    c.trace_failed = false;
+    if (!ok) {
+        drop_schedule(p);
+        return;
+    }
+    // dataflow depth: behind the last writer of everything the node reads, and behind every earlier reader or writer of
+    // what it writes (the trace hands out fresh arrays, so the latter only orders a node behind its own inputs' users)
+    std::map<const void *, int> wrote, read;
+    auto depth_of = [](const std::map<const void *, int> &m, const void *k) {
+        const auto it = m.find(k);
+        return it == m.end() ? 0 : it->second;
+    };
+    std::vector<int> depth(p->ops.size(), 0);
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const NodeOp &o = p->ops[i];
+        const void *in[3] = {o.F, (o.kind != 2 && o.pre == 0) ? (const void *)o.src : nullptr, o.coarse};
+        const void *out[2] = {(o.kind == 2 || !o.no_out) ? (const void *)o.dst : nullptr, o.Fc};
+        int d = 0;
+        for (const void *q : in)
+            if (q) d = std::max(d, depth_of(wrote, q));
+        for (const void *q : out)
+            if (q) d = std::max(d, std::max(depth_of(wrote, q), depth_of(read, q)));
+        depth[i] = ++d;
+        for (const void *q : in)
+            if (q) read[q] = std::max(depth_of(read, q), d);
+        for (const void *q : out)
+            if (q) wrote[q] = d;
+    }
+    // groups: same depth, same shape (file order inside a group; groups in order of depth, then of their first node)
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        mg_cycle_plan::Group *g = nullptr;
+        for (auto &cand : p->sched)
+            if (cand.depth == depth[i] && same_shape(p, p->ops[(size_t)cand.first], p->ops[i])) { g = &cand; break; }
+        if (!g) {
+            p->sched.emplace_back();
+            g = &p->sched.back();
+            g->depth = depth[i];
+            g->first = (int)i;
+        }
+        g->members.push_back((int)i);
+    }
+    std::stable_sort(p->sched.begin(), p->sched.end(), [](const mg_cycle_plan::Group &a, const mg_cycle_plan::Group &b) {
+        return a.depth != b.depth ? a.depth < b.depth : a.first < b.first;
+    });
+    p->sched_max_batch = 0;
+    for (const auto &g : p->sched) p->sched_max_batch = std::max(p->sched_max_batch, (int)g.members.size());
+    if (p->sched_max_batch < 2) {   // nothing to merge: the interpreter does the same launches with less memory
+        drop_schedule(p);
+        return;
+    }
+    // exact-solver state: a slot per coarse-tail instance; the instance tables of all groups in one device array
+    if (!p->tails.empty()) {
+        p->gs_slots = (int *)p->pool.get(2 * p->tails.size() * sizeof(int));
+        if (!p->gs_slots) { drop_schedule(p); return; }
+        for (size_t t = 0; t < p->tails.size(); ++t) p->tails[t].gs_state = p->gs_slots + 2 * t;
+    }
+    std::vector<char> host;
+    for (auto &g : p->sched) {
+        g.items_at = host.size();
+        for (int m : g.members) {
+            const NodeOp &o = p->ops[(size_t)m];
+            if (o.kind == 2) {
+                const k::TailArgs &a = p->tails[(size_t)o.tail];
+                const TailBatchItem it{a.F_top, a.U_top, a.err_dev, a.gs_state};
+                host.insert(host.end(), (const char *)&it, (const char *)&it + sizeof it);
+                p->last_tail = std::max(p->last_tail, o.tail);
+            } else {
+                const NodeBatchItem it{o.src, o.F, o.coarse, o.dst, o.Fc};
+                host.insert(host.end(), (const char *)&it, (const char *)&it + sizeof it);
+                g.errs.push_back(o.err);
+            }
+        }
+        while (host.size() % 16) host.push_back(0);
+    }
+    if (hipMalloc(&p->sched_items, host.size()) != hipSuccess || hipMemcpy(p->sched_items, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_schedule(p);
+        return;
+    }
+    p->pool.park(false);   // (what the trace set aside stays set aside: those are the arrays of the schedule)
+    p->final_U = p->levels->last()->U;
+    p->final_N = p->levels->last()->N;
+    p->sched_ready = true;
+    if (getenv("MG_CYCLE_DEBUG")) {
+        fprintf(stderr, "[cycle] batched schedule: %zu nodes in %zu launches (largest batch %d), %.1f MiB of arrays\n", p->ops.size(), p->sched.size(),
+                p->sched_max_batch, (double)p->pool.bytes_held() / 1048576.0);
+        for (const auto &g : p->sched)
+            fprintf(stderr, "   depth %2d  %-44s N=%5d x%zu\n", g.depth, p->ops[(size_t)g.first].kind == 2 ? "coarse_tail" : p->ops[(size_t)g.first].name,
+                    p->ops[(size_t)g.first].N, g.members.size());
+    }
+}
+
+// one window of a plan with a schedule: its launches, in dataflow order, on the engine's stream
+void replay_schedule(mg_cycle_plan *p)
+{
+    Context &c = ctx();
+    c.defer_norms = true;
+    // the norms of the window are reduced at its end: a reduction in mid-window recycles the arena of partial sums, and a
+    // batch registers its instances one by one (the arena is sized for a whole window when the previous one ends)
+    c.norms_at_window_end = true;
+    for (const auto &g : p->sched) {
+        const NodeOp &o = p->ops[(size_t)g.first];
+        const int n = (int)g.members.size();
+        if (o.kind == 2) {
+            ProfScope ps(n > 1 ? "coarse_tail (batch)" : "coarse_tail", o.N, 0.0);
+            k::tail_launch(c.stream, p->tails[(size_t)o.tail], n, (const TailBatchItem *)((const char *)p->sched_items + g.items_at));
+        } else if (n == 1) {
+            replay_node(o, nullptr);
+        } else {
+            NodeBatch b;
+            b.n = n;
+            b.dev = (const NodeBatchItem *)((const char *)p->sched_items + g.items_at);
+            b.err_outs = g.errs.data();
+            replay_node(o, &b);
         }
     }
-    if (!points) return;
-    p->gs_slots = (int *)p->pool.get(2 * p->err_cap * sizeof(int));
-    if (!p->gs_slots) return;
-    for (int i = 0; i < n_streams; ++i) {
-        hipStream_t t = nullptr;
-        if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        p->side.push_back(t);
-    }
-    p->fork = !p->side.empty();
-    p->fork_max_N = max_n;
+    flush_norms();
+    c.defer_norms = false;
+    c.norms_at_window_end = false;
+    // mg_lastExactSolverIterations(): the state of the LAST coarse-tail slice of the file (each instance has its own slot)
+    if (p->last_tail >= 0)
+        (void)hipMemcpyAsync(c.gs_state, p->gs_slots + 2 * p->last_tail, 2 * sizeof(int), hipMemcpyDeviceToDevice, c.stream);
 }
 
 bool uses_trigger(const mg_cycle_plan *p)
@@ -950,7 +1081,6 @@ mg_cycle_plan *mg_cycle_load(const char *path, int flags)
         delete p;
         return nullptr;
     }
-    if ((flags & MG_CYCLE_FUSED) && !mixed && p->con_N == 1 && p->con_step >= 1 && p->err_dev) plan_forks(p);
     p->levels = new LevelList(&p->pool, mixed ? sizeof(float) : sizeof(double));
     p->levels->Push_back(p->N_max);  // :149
     LevelNode *top = p->levels->last();
@@ -988,12 +1118,11 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     if (!require_ready("mg_cycle_enqueue") || !p) return 1;
     Context &c = ctx();
     hipStream_t s = c.stream;
-    // (a plan that forks its independent sub-cycles onto side streams is not captured: hipStreamEndCapture of that
-    // multi-stream capture crashed inside the ROCm 7.2 runtime for W-cycles from N = 4096 on -- it worked up to 2048 --
-    // and the eager forked window is 2.4 times faster than the replayed serial one anyway: 4.1 against 10.1 ms at 8192)
     const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
-                            !uses_trigger(p) && !p->graph_failed && !p->fork;
+                            !uses_trigger(p) && !p->graph_failed;
     int status = 0;
+    // first window: does the file's dataflow allow a batched schedule (independent visits of a level in one launch)?
+    if (!p->sched_tried) build_schedule(p);
     c.profile_window++;
     (void)hipEventRecord(p->ev0, s);
 
@@ -1009,7 +1138,34 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
             k::convert_to_f32(s, (float *)p->levels->first()->F, p->F64, n_top);
             p->F32_stale = false;
         }
-        for (int it = 0; it < outer && status == 0; ++it) {
+        if (p->sched_ready) {
+            // the schedule is static (arrays, records and report were fixed by the trace): its launches, nothing else
+            const bool capture_now = want_graph && p->warm_runs >= 1;  // run 0 warms the tables and the norm arena
+            bool capturing = false;
+            if (capture_now) {
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+                else { (void)hipGetLastError(); p->graph_failed = true; }
+            }
+            replay_schedule(p);
+            status = c.last_error ? 10 : 0;
+            if (capturing) {
+                hipGraph_t g = nullptr;
+                const hipError_t e = hipStreamEndCapture(s, &g);
+                if (e == hipSuccess && status == 0 && hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    p->graph = g;
+                    p->graph_ready = true;
+                    if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+                } else {
+                    (void)hipGetLastError();
+                    if (g) (void)hipGraphDestroy(g);
+                    p->graph_failed = true;
+                    replay_schedule(p);   // an eager pass, so that this window still produces the result
+                    status = c.last_error ? 10 : 0;
+                }
+            }
+            p->warm_runs++;
+        }
+        for (int it = 0; it < outer && status == 0 && !p->sched_ready; ++it) {
         reset_levels(p);  // records/report: those of the last fp32 cycle
         c.active_pool = &p->pool;
         if (it > 0) {
@@ -1026,10 +1182,10 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
             else { (void)hipGetLastError(); p->graph_failed = true; }
         }
         static const bool dbg = getenv("MG_CYCLE_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[cycle] run_nodes: capturing=%d fork=%d\n", (int)x.capturing, (int)p->fork);
+        if (dbg) fprintf(stderr, "[cycle] run_nodes: capturing=%d\n", (int)x.capturing);
         run_nodes(x);
         status = x.status;
-        if (dbg) fprintf(stderr, "[cycle] run_nodes done: status %d, events %zu, tail launches %d\n", status, p->events_used, p->tail_launches);
+        if (dbg) fprintf(stderr, "[cycle] run_nodes done: status %d\n", status);
         if (x.capturing) {
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(s, &g);
@@ -1184,14 +1340,7 @@ void mg_cycle_destroy(mg_cycle_plan *p)
         p->levels->clear();
         delete p->levels;
     }
-    for (hipStream_t t : p->side) {
-        (void)hipStreamSynchronize(t);
-        (void)hipStreamDestroy(t);
-    }
-    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
-    p->pool.park(false);
-    p->pool.release_parked();
-    if (p->gs_slots) p->pool.put(p->gs_slots);
+    drop_schedule(p);   // (the arrays the trace set aside go back to the pool)
     if (p->err_dev) p->pool.put(p->err_dev);
     if (p->refine_err_dev) p->pool.put(p->refine_err_dev);
     if (p->F64) p->pool.put(p->F64);

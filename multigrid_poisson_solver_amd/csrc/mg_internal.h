@@ -94,6 +94,8 @@ private:
 // one-row-per-block pair kernel): lets the bench report the S = 1 streaming kernel's own rate
 enum Smoother { SMOOTHER_STREAM = 0, SMOOTHER_SIMPLE = 1, SMOOTHER_STREAM_ONLY = 2 };
 
+struct NodeOp;   // (below: one fused node launch as the cycle driver's dataflow trace records it)
+
 struct Context {
     bool ready = false;
     int device = -1;
@@ -102,6 +104,9 @@ struct Context {
     int n_cu = 256;
     Pool pool;
     Pool *active_pool = nullptr;           // plan-private arena while a cycle plan executes
+    int recompute_min_override = 0;        // > 0 while a batched schedule is traced: the recomputing node pair from this N on
+    std::vector<NodeOp> *trace = nullptr;  // != nullptr: fused nodes are recorded, not launched (mg_cycle.cpp: build_schedule)
+    bool trace_failed = false;             // ... and one of them was not a single fused launch
     Smoother smoother = SMOOTHER_STREAM;
     int source_mode = 0;                   // mg_set_source: 0 auto (device when it reproduces the host's libm bit for bit), 1 host, 2 device
     int source_identical = -1;             // result of the self-check: -1 not run yet, 0 differs, 1 identical
@@ -195,6 +200,47 @@ void comm_allgather(const double *send, double *recv, size_t count_per_rank);
 // small host helper: run fn(begin,end) over [0,n) on the host threads
 void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *arg, size_t serial_below = 4096);
 
+// A batch of instances of one fused node: the independent visits of one level that a cycle file's dataflow allows to
+// run side by side (mg_cycle.cpp: every `-1` node starts from the zero field, so the sub-cycles of a W-cycle below one
+// level depend on that level's F alone).  One launch carries all of them: blockIdx.y (coarse tail: blockIdx.x) picks
+// the instance, whose arrays come from a table in device memory.  Type-erased: the fp64 and the fp32 kernels share it.
+struct NodeBatchItem {
+    const void *in, *F, *coarse;   // level-0 input (nullptr: zero / recomputed), source, coarse grid of a fused prolongation
+    void *out, *Fc;                // smoothed field, next level's F of a fused restriction
+};
+struct NodeBatch {
+    int n = 0;
+    const NodeBatchItem *dev = nullptr;     // [n] in device memory
+    double *const *err_outs = nullptr;      // [n] on the host: where each instance's smoothing error goes (device addresses)
+};
+struct TailBatchItem {
+    const void *F_top;
+    void *U_top;
+    double *err_dev;    // the instance's error slots (node.err_slot counts from here)
+    int *gs_state;
+};
+// One fused node launch as the cycle driver's dataflow trace records it (mg_cycle.cpp: build_schedule): while
+// Context::trace is set, the fused-node entry points describe their launch here instead of enqueueing it.
+struct NodeOp {
+    int kind = 0;                 // 0: streaming kernel, 1: register-tile kernel, 2: coarse tail (tail = index of its TailArgs)
+    int N = 0;
+    double L = 1.0;
+    const double *src = nullptr;  // level-0 input (nullptr: zero start, or recomputed when pre > 0)
+    double *F = nullptr, *dst = nullptr;
+    int take = 0;                 // sweeps
+    double *err = nullptr;        // device slot of the smoothing error
+    int d_sign = -1;
+    const double *coarse = nullptr;
+    int Nc = 0;
+    double *Fc = nullptr;
+    int M = 0;
+    int pre = 0;
+    bool no_out = false;
+    int tail = -1;
+    char name[48] = {0};
+    double bytes = 0.0;
+};
+
 // ---------------------------------------------------------------------------
 // kernel launchers (mg_kernels.hip).  All enqueue on s and return immediately.
 // ---------------------------------------------------------------------------
@@ -207,7 +253,7 @@ void residual(hipStream_t s, int N, double inv, const double *U, const double *F
 void smoothing_error(hipStream_t s, int N, double inv, const double *U, const double *F, double *out);
 // second stage of doSmoothing's error: *out = (sum+sum)/N/N over n per-block partials
 void finish_smoothing_error(hipStream_t s, const double *part, size_t n, int N, double *out);
-constexpr int MAX_NORMS_PER_FLUSH = 48;
+constexpr int MAX_NORMS_PER_FLUSH = 160;   // (the descriptors travel as kernel arguments: 24 B each, 4 KB at most)
 struct NormBatch {
     const double *part[MAX_NORMS_PER_FLUSH];
     double *out[MAX_NORMS_PER_FLUSH];
@@ -233,7 +279,10 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
                    const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr,
                    // pre > 0 (fused `1` node): `in` is not read, it is recomputed as `pre` sweeps from zero on F;
                    // no_out (fused `-1` node): the smoothed field is not stored (its `1` node will recompute it)
-                   int pre = 0, bool no_out = false);
+                   int pre = 0, bool no_out = false,
+                   // batch: the same node on batch->n instances in one launch (in/F/out/coarse/Fc above then only tell the
+                   // node's shape -- which of them a node of this kind has -- and err_out is ignored)
+                   const NodeBatch *batch = nullptr);
 // register-tile fused nodes of the small levels (mg_tile.hip / mg_tile_f32.hip): one launch = level 0 (zero | in | in +
 // P(coarse)), `steps` sweeps, the error norm, optionally the d_sign-ed residual restricted into Fc; whole grid only
 bool tile_wanted(int N);      // MG_TILE_MIN_N <= N <= MG_TILE_MAX_N
@@ -244,7 +293,7 @@ int  tile_max_steps();
 void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out, int steps,
                  double *err_out, int d_sign, const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
                  const RestrictTable *rt, bool no_out, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
-                 const RowWindow *fc_w = nullptr);
+                 const RowWindow *fc_w = nullptr, const NodeBatch *batch = nullptr);   // batch: as in jacobi_stream
 void jacobi_tile_f32(hipStream_t s, int N, float dx2, float inv, const float *in, const float *F, float *out, int steps,
                      double *err_out, int d_sign, const float *coarse, int Nc, const ProlongTable *pt, float *Fc, int M,
                      const RestrictTable *rt, bool no_out, const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr,
@@ -306,13 +355,14 @@ struct TailArgsT {
     T *U_top;
     double *err_dev;   // norms are fp64 whatever the field type
     int *gs_state;
+    const TailBatchItem *batch;   // != nullptr: blockIdx.x picks the instance's F_top / U_top / err_dev / gs_state
     TailNode nodes[TAIL_MAX_NODES];
 };
 typedef TailArgsT<double> TailArgs;
 typedef TailArgsT<float> TailArgsF;
 void tail_launch_f32(hipStream_t s, const TailArgsF &a);
 bool tail_fits(const TailArgs &a);
-void tail_launch(hipStream_t s, const TailArgs &a);
+void tail_launch(hipStream_t s, const TailArgs &a, int n_batch = 1, const TailBatchItem *batch_dev = nullptr);
 // red-black Gauss-Seidel to tolerance, fully on device; iterations -> state[1]
 void gauss_seidel(hipStream_t s, int N, double h2, double inv, double *U, const double *F, double tol,
                   int *state);
@@ -326,6 +376,8 @@ int  gs_single_workgroup_max_n();
 // expressions, the same bits, two array passes less.
 bool recompute_available(int Nc, int N, int pre, int step);
 int  recompute_min_n();   // MG_RECOMPUTE_MIN_N (default 4096)
+// launch a recorded fused node on n instances (batch == nullptr: on the arrays recorded in op itself)
+void replay_node(const NodeOp &op, const NodeBatch *batch);
 void smooth_restrict_no_out(int N, double L, double *U_unused, double *F, int step, double *error_dev, int M, double *F_c);
 void prolong_smooth_recompute(int Nc, const double *U_c, int N, double L, double *U_out, double *F, int pre, int step, double *error_dev);
 // the same pair on fp32 fields (mixed-precision mode); U_out_wide != nullptr: the result is stored in fp64 there

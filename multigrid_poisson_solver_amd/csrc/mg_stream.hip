@@ -15,7 +15,7 @@ bool stream_recompute_supported(int pre, int steps) { return f64::recompute_inst
 void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out,
                    int steps, double *err_out, double *D_out, int d_sign, const double *coarse, int Nc,
                    const ProlongTable *pt, double *Fc, int M, const RestrictTable *rt, const RowWindow *fine_w,
-                   const RowWindow *coarse_w, const RowWindow *fc_w, int pre, bool no_out)
+                   const RowWindow *coarse_w, const RowWindow *fc_w, int pre, bool no_out, const NodeBatch *batch)
 {
     f64::StreamTables tb;
     if (coarse) {
@@ -33,7 +33,7 @@ void jacobi_stream(hipStream_t s, int N, double dx2, double inv, const double *i
         tb.r_w = rt->w;
         tb.r_wf = rt->inv_w;
     }
-    f64::run(s, N, dx2, inv, in, F, out, steps, err_out, D_out, d_sign, coarse, Nc, Fc, M, tb, fine_w, coarse_w, fc_w, nullptr, pre, no_out);
+    f64::run(s, N, dx2, inv, in, F, out, steps, err_out, D_out, d_sign, coarse, Nc, Fc, M, tb, fine_w, coarse_w, fc_w, nullptr, pre, no_out, batch);
 }
 
 }  // namespace k

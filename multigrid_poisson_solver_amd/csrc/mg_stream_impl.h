@@ -142,6 +142,13 @@ struct StreamParams {
     const int *r_inv;   // [N] fine index -> coarse index whose lower-left sample it is, or -1
     const real_t *r_w;  // [M] weights by coarse index
     const real_t *r_wf; // [N] r_w[r_inv[x]] by fine index (0 where r_inv < 0)
+    // A BATCH of instances of the same node (the independent visits of one level in a W-cycle, mg_cycle.cpp): blockIdx.y
+    // picks the instance, whose arrays replace in / F / out / Fc / coarse; its norm partials follow those of the
+    // instance before it.  nullptr: the one instance described above.
+    const NodeBatchItem *batch;
+    int part_stride;    // partials per instance
+    int n_batch;                // (host side only: instances of the launch, and where each one's error goes)
+    double *const *err_outs;
 };
 
 
@@ -347,6 +354,20 @@ void k_jacobi_stream(const StreamParams p)
     const int per_xcd = (p.n_blocks + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile >= p.n_blocks) return;
+    // the arrays of this instance (wave-uniform; a batch reads them through the constant address space: scalar loads)
+    const real_t *a_in = p.in, *a_F = p.F, *a_coarse = p.coarse;
+    real_t *a_out = p.out, *a_Fc = p.Fc;
+    double *a_part = p.part;
+    if (p.batch) {
+        typedef const NodeBatchItem __attribute__((address_space(4))) *item_ptr;
+        const item_ptr b = (item_ptr)(uintptr_t)(p.batch + blockIdx.y);
+        a_in = static_cast<const real_t *>(b->in);
+        a_F = static_cast<const real_t *>(b->F);
+        a_coarse = static_cast<const real_t *>(b->coarse);
+        a_out = static_cast<real_t *>(b->out);
+        a_Fc = static_cast<real_t *>(b->Fc);
+        if (a_part) a_part += (size_t)blockIdx.y * (size_t)p.part_stride;
+    }
     const int chunk = tile / p.groups;
     const int group = tile - chunk * p.groups;
 
@@ -356,7 +377,7 @@ void k_jacobi_stream(const StreamParams p)
     const int N = p.N;
     const int own_x0 = strip * OW;
     if (own_x0 >= N) {  // no barriers in this kernel: a wave may leave at any time
-        if (p.part && lane == 0) p.part[(size_t)tile * WAVES_PER_WG + wave] = 0.0;
+        if (a_part && lane == 0) a_part[(size_t)tile * WAVES_PER_WG + wave] = 0.0;
         return;
     }
     const int y0 = p.own_y0 + chunk * p.rows_per_chunk;
@@ -478,7 +499,7 @@ void k_jacobi_stream(const StreamParams p)
     if constexpr (RESTRICT) {
         for (int edge = 0; edge < 2; ++edge) {
             if (edge == 0 ? (y0 != 0) : (y1 != N)) continue;
-            real_t *row = p.Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
+            real_t *row = a_Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
 #pragma unroll
             for (int q = 0; q < NS; ++q)
                 if (rc_col[q] >= 0) row[rc_col[q]] = 0.0;
@@ -584,7 +605,7 @@ void k_jacobi_stream(const StreamParams p)
     // wave-uniform row addresses, in bytes.  The load address follows the CLAMPED input row (every load is issued, see
     // load_row): it moves on only while the next row lies inside the window; the store address follows the unclamped
     // output row (stores are predicated).
-    const char *in_b = reinterpret_cast<const char *>(p.in), *f_b = reinterpret_cast<const char *>(p.F);
+    const char *in_b = reinterpret_cast<const char *>(a_in), *f_b = reinterpret_cast<const char *>(a_F);
     const int yc_first = y_first < av_lo ? av_lo : (y_first < av_hi ? y_first : av_hi - 1);
     unsigned long long ld_off = (unsigned long long)(yc_first - p.row_base) * row_bytes;  // row of the next load
     int ld_t = 0;                                                                          // its step index (row y_first + ld_t)
@@ -604,7 +625,7 @@ void k_jacobi_stream(const StreamParams p)
             // (never consumed).  Scalar arithmetic on the wave-uniform owner (a second table register cost two VGPRs)
             const int cr = own_s + 1 - p.coarse_base;
             const int crc = cr < 0 ? 0 : (cr < p.coarse_rows - 1 ? cr : p.coarse_rows - 1);
-            pc[u8 % NU] = load_coarse_local<NCV>(p.coarse, p.Nc, crc, pc_col);
+            pc[u8 % NU] = load_coarse_local<NCV>(a_coarse, p.Nc, crc, pc_col);
         }
         ++ld_t;
         // the clamped row moves on only inside the window: av_lo < y_first + ld_t < av_hi
@@ -618,7 +639,7 @@ void k_jacobi_stream(const StreamParams p)
         const int ys = yp_first > av_lo ? yp_first : av_lo;
         if (ys < av_hi && ys < y_end) {
             const int i0 = table_i(p.p_orow, ys);
-            const CoarseV<NCV> c0 = load_coarse<NCV>(p.coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
+            const CoarseV<NCV> c0 = load_coarse<NCV>(a_coarse, p.Nc, p.coarse_base, p.coarse_rows, i0, pc_col);
             interpolate(c0, hB);
             c_row = i0 - 1;
         }
@@ -824,7 +845,7 @@ void k_jacobi_stream(const StreamParams p)
                             for (int j = 0; j < COLS; ++j) __builtin_nontemporal_store((double)nw.v[j], w + j);
                         }
                     } else {
-                        store_row<COLS, NT>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(p.out) + st_off), col_st, nw);
+                        store_row<COLS, NT>(reinterpret_cast<real_t *>(reinterpret_cast<char *>(a_out) + st_off), col_st, nw);
                     }
                 }
             }
@@ -892,7 +913,7 @@ void k_jacobi_stream(const StreamParams p)
                         const real_t wc = lane_value(tb_rw, t & 63), wd = real_t(1.0) - wc;  // c, d of :664-666
                         const real_t p_up = from_lane_above(d_prev.v[0]);
                         const real_t q_up = from_lane_above(d.v[0]);
-                        real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
+                        real_t *crow = a_Fc + (size_t)(rc_row - p.fc_base) * p.M;
 #pragma unroll
                         for (int q = 0; q < NS; ++q) {
                             // the column after the pair: the lane's next pair, or the next lane's first column
@@ -935,10 +956,10 @@ void k_jacobi_stream(const StreamParams p)
         }
     }
 #endif
-    if (p.part) {
+    if (a_part) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) p.part[(size_t)tile * WAVES_PER_WG + wave] = acc;
+        if (lane == 0) a_part[(size_t)tile * WAVES_PER_WG + wave] = acc;
     }
 }
 
@@ -966,7 +987,8 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     const int groups = (strips + WAVES_PER_WG - 1) / WAVES_PER_WG;
     static const int resident_pct = [] { const char *e = getenv("MG_RESIDENT_PCT"); return e ? atoi(e) : 100; }();
     const int resident = ctx().n_cu * blocks_per_cu * resident_pct / 100;
-    int chunks = resident / groups;
+    const int nb = p.batch ? p.n_batch : 1;   // the instances of a batch share the resident round
+    int chunks = resident / (groups * nb);
     // small grids are latency bound on the length of a wave's march: shorter chunks, more waves
     static const int min_rows_forced = [] { const char *e = getenv("MG_MIN_ROWS"); return e ? atoi(e) : 0; }();
     const int min_rows = min_rows_forced ? min_rows_forced : (N <= 256 ? 2 : N <= 1024 ? 4 : 8);
@@ -994,12 +1016,14 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     p.trace = trace_dev;
 #endif
     const size_t n_part = (size_t)p.n_blocks * WAVES_PER_WG;
-    if (err_out) {
-        p.part = norm_partials(n_part);  // every wave of every tile writes its slot
+    const bool want_norm = err_out || (p.batch && p.err_outs);
+    if (want_norm) {
+        p.part = norm_partials(n_part * (size_t)nb);  // every wave of every tile writes its slot
         if (!p.part) return;
     }
-    const int grid = ((p.n_blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT, PRE>), dim3(grid), dim3(64 * WAVES_PER_WG), 0, s, p);
+    p.part_stride = (int)n_part;
+    const int grid = ((p.n_blocks + 7) / 8) * 8;   // (a multiple of 8: with x fastest in the dispatch order, x & 7 stays the XCD of a workgroup for every y)
+    hipLaunchKernelGGL((k_jacobi_stream<S, COLS, IN, RESTRICT, PF, NT, PRE>), dim3(grid, nb), dim3(64 * WAVES_PER_WG), 0, s, p);
 #ifdef MG_STREAM_TRACE
     {
         long long t[4];
@@ -1039,7 +1063,12 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
     }
 #endif
     // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
-    if (err_out) norm_finish(s, p.part, n_part, p.raw_norm ? -1 : N, err_out);
+    if (p.batch && p.err_outs) {
+        for (int i = 0; i < nb; ++i)
+            if (p.err_outs[i]) norm_finish(s, p.part + (size_t)i * n_part, n_part, p.raw_norm ? -1 : N, p.err_outs[i]);
+    } else if (err_out) {
+        norm_finish(s, p.part, n_part, p.raw_norm ? -1 : N, err_out);
+    }
 }
 
 template <int S, int PF>
@@ -1113,8 +1142,12 @@ void launch_steps(hipStream_t s, const StreamParams &p, double *err_out)
 inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps,
                 double *err_out, real_t *D_out, int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M,
                 const StreamTables &tb, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
-                double *out_wide = nullptr, int pre = 0, bool no_out = false)
+                double *out_wide = nullptr, int pre = 0, bool no_out = false, const NodeBatch *batch = nullptr)
 {
+    if (batch && (fine_w || coarse_w || fc_w || D_out || out_wide || batch->n < 1)) {
+        fail(MG_ERR_ARG, "jacobi_stream: a batch of instances runs whole grids without a stored residual");
+        return;
+    }
     if (pre != 0 && !(recompute_instantiated(pre, steps) && coarse && !Fc)) {
         fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 1+1, 2+2 and 3+3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
         return;
@@ -1132,6 +1165,11 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         return;
     }
     StreamParams p = {};
+    if (batch) {
+        p.batch = batch->dev;
+        p.n_batch = batch->n;
+        p.err_outs = batch->err_outs;
+    }
     p.N = N;
     p.dx2 = dx2;
     p.inv = inv;

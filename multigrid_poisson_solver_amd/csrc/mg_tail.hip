@@ -22,7 +22,7 @@ void gauss_seidel_blocks_launch(hipStream_t s, int N, double h2, double inv, dou
 }
 
 bool tail_fits(const TailArgs &a) { return f64::tail_lds_bytes(a) <= (size_t)(160 * 1024 - 512); }
-void tail_launch(hipStream_t s, const TailArgs &a) { f64::tail_launch(s, a); }
+void tail_launch(hipStream_t s, const TailArgs &a, int n_batch, const TailBatchItem *batch_dev) { f64::tail_launch(s, a, n_batch, batch_dev); }
 
 }  // namespace k
 }  // namespace mg

@@ -513,6 +513,20 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     // lane l: level l) and are fetched with v_readlane.  Read from the kernel arguments with a run-time index they are
     // scalar loads, and a lone dependent scalar load costs a wave ~250 cycles: several per node, and one in every
     // sweep for the offset of the level's arrays, were a third of a node's time on the 16 x 16 level.
+    // the arrays of this instance: a batch (the independent coarse-tail slices of a W-cycle, one workgroup each) reads them
+    // from a table in device memory
+    const real_t *a_F_top = a.F_top;
+    real_t *a_U_top = a.U_top;
+    double *a_err_dev = a.err_dev;
+    int *a_gs_state = a.gs_state;
+    if (a.batch) {
+        typedef const TailBatchItem __attribute__((address_space(4))) *item_ptr;
+        const item_ptr b = (item_ptr)(uintptr_t)(a.batch + blockIdx.x);
+        a_F_top = static_cast<const real_t *>(b->F_top);
+        a_U_top = static_cast<real_t *>(b->U_top);
+        a_err_dev = b->err_dev;
+        a_gs_state = b->gs_state;
+    }
     const int tab_lane = threadIdx.x & 63;
     int lv_where = 0, lv_tabs = 0;            // base | N << 16;  real tables | int tables << 16  (offsets < 2^16: 160 KB of LDS)
     real_t lv_dx2 = 0, lv_inv = 0, lv_cdx = 1, lv_crcp = 1;
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     {
         // stage the finest source and all transfer tables: one global round trip for the launch
         const int N0 = N_of(0), f0 = F_of(0);
-        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) lds[f0 + p] = a.F_top[p];
+        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) lds[f0 + p] = a_F_top[p];
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int l = 0; l + 1 < a.n_levels; ++l) {
             const int N = N_of(l), M = N_of(l + 1), rt = real_tab_of(l), it = int_tab_of(l);
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     // and the 600 cycles leave the critical path.
     int pend_slot = -1, pend_N = 0, pend_parity = 0;
     auto flush_error = [&]() {
-        if (pend_slot >= 0 && threadIdx.x == TAIL_THREADS - 64) finish_error(slots[pend_parity], pend_N, a.err_dev + pend_slot);
+        if (pend_slot >= 0 && threadIdx.x == TAIL_THREADS - 64) finish_error(slots[pend_parity], pend_N, a_err_dev + pend_slot);
         pend_slot = -1;
     };
     const int n_nodes = a.n_nodes;
@@ -684,15 +698,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
             const int N = N_of(cur);
             const double gs_h2 = lane_get(lv_gs_h2, cur), gs_inv = lane_get(lv_gs_inv, cur);
             if (N * N <= 64 && (N & 1) == 0 && N >= 4) {
-                gauss_seidel_blocks(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a.gs_state);
+                gauss_seidel_blocks(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a_gs_state);
             } else if (N * N <= 64) {
-                gauss_seidel_wave(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a.gs_state);
+                gauss_seidel_wave(N, gs_h2, gs_inv, U_of(cur), F_of(cur), nd.tol, a_gs_state);
             } else if (N * N <= 64 * GS_WAVE_PTS) {
                 // fp64 fields: the level's own U array is the solver's array; fp32 fields: the fp64 scratch
                 const bool in_place = sizeof(real_t) == sizeof(double);
                 gauss_seidel_wave_lds(N, gs_h2, gs_inv, in_place ? U_of(cur) : gs_scratch(a), in_place, U_of(cur), F_of(cur),
-                                      nd.tol, a.gs_state);
-            } else gauss_seidel_level(N, gs_h2, gs_inv, U_of(cur), F_of(cur), gs_scratch(a), nd.tol, sm, a.gs_state);
+                                      nd.tol, a_gs_state);
+            } else gauss_seidel_level(N, gs_h2, gs_inv, U_of(cur), F_of(cur), gs_scratch(a), nd.tol, sm, a_gs_state);
             __syncthreads();
         } else {  // 1: doProlongation :354, doGridAddition :368, doSmoothing :416
             const int Nc = N_of(cur), fine = cur - 1, N = N_of(fine);
@@ -770,7 +784,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgsT<real_t> a
     if (a.trace && threadIdx.x == 0) a.trace[1 + a.n_nodes] = wall_clock64();
     {
         const int N0 = N_of(0), u0 = U_of(0);
-        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) a.U_top[p] = lds[u0 + p];
+        for (int p = threadIdx.x; p < N0 * N0; p += TAIL_THREADS) a_U_top[p] = lds[u0 + p];
     }
 }
 
@@ -809,7 +823,7 @@ inline TailLayout tail_layout(const TailArgsT<real_t> &a)
 }
 inline size_t tail_lds_bytes(const TailArgsT<real_t> &a) { return tail_layout(a).bytes; }
 
-inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
+inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a, int n_batch = 1, const TailBatchItem *batch_dev = nullptr)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -820,7 +834,8 @@ inline void tail_launch(hipStream_t s, const TailArgsT<real_t> &a)
     TailArgsT<real_t> b = a;
     b.tab_real0 = L.tab_real0;
     b.tab_int0 = L.tab_int0;
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(TAIL_THREADS), L.bytes, s, b);
+    b.batch = batch_dev;   // one workgroup (one CU: the levels fill its LDS) per instance
+    hipLaunchKernelGGL(k_tail, dim3(batch_dev ? n_batch : 1), dim3(TAIL_THREADS), L.bytes, s, b);
 }
 
 }  // namespace MG_REAL_NS

@@ -28,7 +28,8 @@ int tile_max_steps() { return f64::tile::MAX_S; }
 
 void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in, const double *F, double *out, int steps,
                  double *err_out, int d_sign, const double *coarse, int Nc, const ProlongTable *pt, double *Fc, int M,
-                 const RestrictTable *rt, bool no_out, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w)
+                 const RestrictTable *rt, bool no_out, const RowWindow *fine_w, const RowWindow *coarse_w, const RowWindow *fc_w,
+                 const NodeBatch *batch)
 {
     f64::tile::Tables tb;
     if (coarse) {
@@ -47,7 +48,7 @@ void jacobi_tile(hipStream_t s, int N, double dx2, double inv, const double *in,
         tb.r_w = rt->w;
         tb.r_wf = rt->inv_w;
     }
-    f64::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out, fine_w, coarse_w, fc_w);
+    f64::tile::run(s, N, dx2, inv, in, F, out, steps, err_out, d_sign, coarse, Nc, Fc, M, tb, no_out, fine_w, coarse_w, fc_w, batch);
 }
 
 }  // namespace k

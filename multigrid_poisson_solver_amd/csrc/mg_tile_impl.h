@@ -79,6 +79,11 @@ struct TileParams {
     const int *r_inv;   // [N] fine index -> interior coarse index whose lower-left sample it is, or -1
     const real_t *r_w;  // [M] weights by coarse index
     const real_t *r_wf; // [N] r_w[r_inv[x]] by fine index (0 where r_inv < 0)
+    // a batch of instances of the node (mg_internal.h: NodeBatch): blockIdx.y picks the instance's arrays
+    const NodeBatchItem *batch;
+    int part_stride;            // partials per instance
+    int n_batch;                // (host side only)
+    double *const *err_outs;
 };
 
 // window rows/columns beyond the owned tile, per side.  Level s of a point is valid when the point lies at least s rows
@@ -114,6 +119,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     const int per_xcd = (p.n_blocks + 7) >> 3;
     const int tile_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile_id >= p.n_blocks) return;   // (the whole workgroup: no barrier is left waiting)
+    // the arrays of this instance (wave-uniform; a batch reads them through the constant address space: scalar loads)
+    const real_t *a_in = p.in, *a_F = p.F, *a_coarse = p.coarse;
+    real_t *a_out = p.out, *a_Fc = p.Fc;
+    double *a_part = p.part;
+    if (p.batch) {
+        typedef const NodeBatchItem __attribute__((address_space(4))) *item_ptr;
+        const item_ptr b = (item_ptr)(uintptr_t)(p.batch + blockIdx.y);
+        a_in = static_cast<const real_t *>(b->in);
+        a_F = static_cast<const real_t *>(b->F);
+        a_coarse = static_cast<const real_t *>(b->coarse);
+        a_out = static_cast<real_t *>(b->out);
+        a_Fc = static_cast<real_t *>(b->Fc);
+        if (a_part) a_part += (size_t)blockIdx.y * (size_t)p.part_stride;
+    }
     const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,10 +192,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     }
     real_t f[RPW], v[RPW];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) f[j] = p.F[(size_t)row_clamped(j) * N + xc];
+    for (int j = 0; j < RPW; ++j) f[j] = a_F[(size_t)row_clamped(j) * N + xc];
     if constexpr (IN != T_ZERO) {
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) v[j] = p.in[(size_t)row_clamped(j) * N + xc];
+        for (int j = 0; j < RPW; ++j) v[j] = a_in[(size_t)row_clamped(j) * N + xc];
     }
     // local row of the coarse window (rows fetched for halo rows of the fine window may lie outside it: clamped, never consumed)
     auto coarse_local = [&](int r) { const int l = r - p.coarse_base; return l < 0 ? 0 : (l < p.coarse_rows - 1 ? l : p.coarse_rows - 1); };
@@ -196,11 +215,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
         for (int j = 0; j < RPW; ++j) {
             own[j] = lane_value(t_own, j);
             const int up = own[j] + 1 < last ? own[j] + 1 : last;
-            const real_t *crow = p.coarse + (size_t)coarse_local(up) * p.Nc;
+            const real_t *crow = a_coarse + (size_t)coarse_local(up) * p.Nc;
             ca[j] = crow[cj];
             cb[j] = crow[cj1];
         }
-        const real_t *crow0 = p.coarse + (size_t)coarse_local(own[0]) * p.Nc;
+        const real_t *crow0 = a_coarse + (size_t)coarse_local(own[0]) * p.Nc;
         c0a = crow0[cj];
         c0b = crow0[cj1];
     }
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
     if (!p.no_out && lane_owns) {
 #pragma unroll
         for (int j = 0; j < RPW; ++j)
-            if (row_owned(j)) p.out[(size_t)(row_y(j) - p.row_base) * N + x] = v[j];
+            if (row_owned(j)) a_out[(size_t)(row_y(j) - p.row_base) * N + x] = v[j];
     }
 
     // ---- residual (:560), error sums (:610/:617), restriction (:656-678) -------------------------------------------
@@ -316,9 +335,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
             const int am = ((j & 1) ? nm_odd : nm_even) & ((row_owned(j) && (unsigned)(yb + j - p.norm_y0) < (unsigned)(p.norm_y1 - p.norm_y0)) ? inner : 0);
             acc += fabs(bits_and((double)r, am));
         }
-        if (p.part) {
+        if (a_part) {
             const double total = wave_sum_dpp(acc);
-            if (lane == 0) p.part[(size_t)tile_id * WAVES + wave] = total;
+            if (lane == 0) a_part[(size_t)tile_id * WAVES + wave] = total;
         }
         if constexpr (RESTRICT) {
             // the row after the block's last one: the next wave's first
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
             if (wave == 0) {
                 for (int edge = 0; edge < 2; ++edge) {
                     if (edge == 0 ? (oy0 != 0) : (oy1 != N)) continue;
-                    real_t *row = p.Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
+                    real_t *row = a_Fc + (size_t)((edge == 0 ? 0 : p.M - 1) - p.fc_base) * p.M;
                     if (rc_col >= 0) row[rc_col] = 0.0;
                     if (first_col_lane) row[0] = 0.0;
                     if (last_col_lane) row[p.M - 1] = 0.0;
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_jacobi_tile(const TileParams p)
                 const real_t u1 = from_lane_above(u0), u3 = from_lane_above(u2);
                 // :676  U_c = b*d*U_f[f] + a*d*U_f[f+1] + c*b*U_f[f+N] + a*c*U_f[f+N+1]
                 const real_t vc = rw_b * wd * u0 + rw_a * wd * u1 + wc * rw_b * u2 + rw_a * wc * u3;
-                real_t *crow = p.Fc + (size_t)(rc_row - p.fc_base) * p.M;
+                real_t *crow = a_Fc + (size_t)(rc_row - p.fc_base) * p.M;
                 if (rc_col >= 0) crow[rc_col] = vc;
                 if (tile_x == 0 && first_col_lane) crow[0] = 0.0;
                 if (ox1 == N && last_col_lane) crow[p.M - 1] = 0.0;
@@ -374,10 +393,12 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out, bool raw_norm)
     p.n_blocks = p.tiles_x * tiles_y;
     p.part = nullptr;
     const size_t n_part = (size_t)p.n_blocks * WAVES;
-    if (err_out) {
-        p.part = norm_partials(n_part);  // every wave of every tile writes its slot
+    const int nb = p.batch ? p.n_batch : 1;
+    if (err_out || (p.batch && p.err_outs)) {
+        p.part = norm_partials(n_part * (size_t)nb);  // every wave of every tile writes its slot
         if (!p.part) return;
     }
+    p.part_stride = (int)n_part;
     const int grid = ((p.n_blocks + 7) / 8) * 8;
 #ifdef MG_TILE_TRACE
     static long long *trace_dev = nullptr;
@@ -385,7 +406,7 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out, bool raw_norm)
     (void)hipMemsetAsync(trace_dev, 0, 8 * sizeof(long long), s);
     p.trace = trace_dev;
 #endif
-    hipLaunchKernelGGL((k_jacobi_tile<S, IN, RESTRICT, RPW, WAVES>), dim3(grid), dim3(64 * WAVES), 0, s, p);
+    hipLaunchKernelGGL((k_jacobi_tile<S, IN, RESTRICT, RPW, WAVES>), dim3(grid, nb), dim3(64 * WAVES), 0, s, p);
 #ifdef MG_TILE_TRACE
     {
         long long t[8];
@@ -397,7 +418,12 @@ void launch_tile(hipStream_t s, TileParams p, double *err_out, bool raw_norm)
     }
 #endif
     // a slab launch leaves its RAW partial sum; the caller combines the slabs in rank order
-    if (err_out) norm_finish(s, p.part, n_part, raw_norm ? -1 : N, err_out);
+    if (p.batch && p.err_outs) {
+        for (int i = 0; i < nb; ++i)
+            if (p.err_outs[i]) norm_finish(s, p.part + (size_t)i * n_part, n_part, raw_norm ? -1 : N, p.err_outs[i]);
+    } else if (err_out) {
+        norm_finish(s, p.part, n_part, raw_norm ? -1 : N, err_out);
+    }
 }
 
 // Window geometry: RPW rows per wave x WAVES waves.  The launch is bound by the instruction stream of a lone wave
@@ -454,8 +480,13 @@ constexpr int MAX_S = 4;
 // stored residual and without the recomputing form (the caller routes those to the streaming kernel)
 inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, const real_t *F, real_t *out, int steps, double *err_out,
                 int d_sign, const real_t *coarse, int Nc, real_t *Fc, int M, const Tables &tb, bool no_out,
-                const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr)
+                const RowWindow *fine_w = nullptr, const RowWindow *coarse_w = nullptr, const RowWindow *fc_w = nullptr,
+                const NodeBatch *batch = nullptr)
 {
+    if (batch && (fine_w || coarse_w || fc_w || batch->n < 1)) {
+        fail(MG_ERR_ARG, "jacobi_tile: a batch of instances runs whole grids");
+        return;
+    }
     if (steps < 1 || steps > MAX_S || N < 8) {
         fail(MG_ERR_ARG, "jacobi_tile: %d sweeps on N=%d (1..%d sweeps, N >= 8)", steps, N, MAX_S);
         return;
@@ -465,6 +496,11 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         return;
     }
     TileParams p = {};
+    if (batch) {
+        p.batch = batch->dev;
+        p.n_batch = batch->n;
+        p.err_outs = batch->err_outs;
+    }
     p.N = N;
     p.dx2 = dx2;
     p.inv = inv;
