@@ -137,7 +137,7 @@ def compulsory_bytes(kernel_family, N):
         return (8.0 if "noU" in kernel_family else 16.0) * n + 8.0 * (N // 2) ** 2
     if "prolong" in kernel_family:    # pre3: the pre-smoothed field is recomputed (3 sweeps from zero), not read
         return (16.0 if "pre" in kernel_family else 24.0) * n + 8.0 * (N // 2) ** 2
-    if "jacobi_stream" in kernel_family or "jacobi_pair" in kernel_family or "jacobi_tile" in kernel_family:
+    if any(f in kernel_family for f in ("jacobi_stream", "jacobi_pair", "jacobi_tile", "slab_stream", "slab_tile")):
         return (16.0 if "zero" in kernel_family else 24.0) * n
     return None
 

@@ -6,7 +6,9 @@ Two legs per run, both in the one JSON line rank 0 prints:
          quoted on, so the grid is N_g x N_g with N_g ~ 8192*sqrt(gpus) (8192, 11520, 16384, 23040 for 1, 2, 4, 8
          GPUs: sizes m * 2^j with m <= 64, so that every level above the coarse-tail kernel keeps an even size);
   strong (`strong_scaling`): the V-cycle at N = 16384^2 (BASELINE.json configs[3]; north_star's >= 6x at 8 GPUs
-         is quoted on it) cut into `gpus` slabs -- the one-GPU base of that curve is in bench.py's N = 1 line.
+         is quoted on it) cut into `gpus` slabs -- the one-GPU base of that curve is in bench.py's N = 1 line;
+         `strong_scaling_8192`: the headline grid itself (BASELINE.json's metric: "8192^2 fp64, 1/2/4/8 GPUs") cut into
+         `gpus` slabs, base = the N = 1 line's `value`; `strong_scaling_32768`: the same one size up.
 `value` is the whole-job aggregate: lattice updates of one V(3,3)-cycle over ALL slabs divided by the slowest
 rank's time.  --scaling strong swaps which leg is `value`.
 
@@ -193,13 +195,13 @@ def run(args, rank, world, local_rank):
 
     tmp = tempfile.mkdtemp(prefix=f"mgbench_r{rank}_")
     N_weak = grid_for(world, args.n, args.mixed) if args.n == 8192 else args.n
-    weak = run_leg(mg, args, rank, world, N_weak, rehearsal_wire, tmp)
+    # The strong-scaling legs run first: they are legs of the line AND the sustained load after which the weak leg -- the
+    # line's `value` -- starts at the clocks a long run holds (bench.py does the same on one GPU).
+    keys = ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error", "rank0_ms_per_step", "ghost_exchanges",
+            "cycle_roofline", "ms_per_step_ranks")
     strong = None
     if not args.no_strong and N_weak != STRONG_N:
         strong = run_leg(mg, args, rank, world, STRONG_N, rehearsal_wire, tmp)
-    elif not args.no_strong:
-        strong = weak  # 4 GPUs: the weak-scaling grid IS 16384^2
-
     large = None
     if not args.no_strong and not getattr(args, "no_large", False) and not args.mixed:
         from bench import LARGE_N
@@ -207,6 +209,15 @@ def run(args, rank, world, local_rank):
         largs = copy.copy(args)
         largs.steps, largs.warmup = min(args.steps, 10), min(max(1, args.warmup), 10)
         large = run_leg(mg, largs, rank, world, LARGE_N, rehearsal_wire, tmp)
+    # BASELINE.json's metric names 8192^2 at 1/2/4/8 GPUs: the headline grid itself cut into `world` slabs (1024 rows per
+    # slab at 8 GPUs: three distributed levels, the hierarchy collapses at 1024) -- a strong leg whose one-GPU base is the
+    # N = 1 line's `value`
+    head_grid = None
+    if not args.no_strong and world > 1 and N_weak != 8192 and not args.mixed:
+        head_grid = run_leg(mg, args, rank, world, 8192, rehearsal_wire, tmp)
+    weak = run_leg(mg, args, rank, world, N_weak, rehearsal_wire, tmp)
+    if not args.no_strong and N_weak == STRONG_N:
+        strong = weak  # 4 GPUs: the weak-scaling grid IS 16384^2
 
     if rank == 0:
         head, other, name = (weak, strong, "strong_scaling")
@@ -225,13 +236,14 @@ def run(args, rank, world, local_rank):
                if rehearsal and world > 1 else {}),
         }
         if other:
-            out[name] = {k: other[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
-                                               "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline", "ms_per_step_ranks")}
+            out[name] = {k: other[k] for k in keys}
             out[name]["scaling"] = "strong" if name == "strong_scaling" else "weak"
         if large:
-            out["strong_scaling_32768"] = {k: large[k] for k in ("N", "n_gpus", "value", "unit", "ms_per_step", "steps", "workload", "mg_error",
-                                                                 "rank0_ms_per_step", "ghost_exchanges", "cycle_roofline", "ms_per_step_ranks")}
+            out["strong_scaling_32768"] = {k: large[k] for k in keys}
             out["strong_scaling_32768"]["scaling"] = "strong"
+        if head_grid:
+            out["strong_scaling_8192"] = {k: head_grid[k] for k in keys}
+            out["strong_scaling_8192"]["scaling"] = "strong"
         print(json.dumps(out), flush=True)
     if world > 1:
         mg.lib().mg_comm_finalize()

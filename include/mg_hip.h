@@ -202,6 +202,9 @@ typedef struct mg_cycle_result {
     int     n_records;
     const mg_node_record *records; /* owned by the plan, valid until the next execute */
     const char *report;    /* the reference's printed report (owned by the plan) */
+    int     graph_replayed;     /* 1: the last window was a hipGraph replay (MG_CYCLE_GRAPH took effect), 0: launched eagerly */
+    int     schedule_launches;  /* > 0: the window ran as a batched breadth-first schedule of this many launches (the
+                                 * independent visits of a level merged into one launch each); 0: node by node */
 } mg_cycle_result;
 
 typedef struct mg_cycle_plan mg_cycle_plan;

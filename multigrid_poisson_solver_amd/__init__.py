@@ -37,7 +37,8 @@ class ProfileEntry(C.Structure):
 class CycleResult(C.Structure):
     _fields_ = [("status", C.c_int), ("N", C.c_int), ("U_dev", C.c_void_p), ("mg_error", C.c_double),
                 ("time_ms", C.c_double), ("device_ms", C.c_double), ("n_records", C.c_int),
-                ("records", C.POINTER(NodeRecord)), ("report", C.c_char_p)]
+                ("records", C.POINTER(NodeRecord)), ("report", C.c_char_p), ("graph_replayed", C.c_int),
+                ("schedule_launches", C.c_int)]
 
 
 _vp, _i, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64
@@ -519,7 +520,8 @@ class CyclePlan:
         out = dict(status=status, N=res.N, mg_error=res.mg_error, time_ms=res.time_ms, device_ms=res.device_ms,
                    records=[(res.records[i].node, res.records[i].N, res.records[i].steps, res.records[i].error)
                             for i in range(res.n_records)],
-                   report=res.report.decode() if res.report else "", U_ptr=res.U_dev)
+                   report=res.report.decode() if res.report else "", U_ptr=res.U_dev,
+                   graph_replayed=bool(res.graph_replayed), schedule_launches=res.schedule_launches)
         if fetch_U:
             U = np.empty((res.N, res.N))
             _lib.mg_download(U.ctypes.data, res.U_dev, U.size)

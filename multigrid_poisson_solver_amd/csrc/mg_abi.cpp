@@ -820,11 +820,11 @@ void slab_smooth(int N, double L, const double *U_in, double *U_out, const doubl
     if (sf.coarse) bytes += 16.0 * n + 2.0 * n;
     char name[48], pre_tag[8] = "";
     if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
-    snprintf(name, sizeof name, "slab_stream<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
+    // a slab of a level the caches hold: the register-tile kernel on the row window (mg_tile_impl.h)
+    const bool as_tile = !sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps();
+    snprintf(name, sizeof name, "%s<%d%s%s%s%s%s>", as_tile ? "slab_tile" : "slab_stream", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
              sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
-    if (!sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps()) {
-        // a slab of a level the caches hold: the register-tile kernel on the row window (mg_tile_impl.h)
-        memcpy(name, "slab_tile  ", 11);
+    if (as_tile) {
         ProfScope ps(name, N, bytes);
         k::jacobi_tile(c.stream, N, dx2, inv, U_in, F, U_out, step, raw_norm_out, -1, sf.coarse, sf.Nc, pt, sf.Fc, sf.M, rt, sf.no_out,
                        &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);
@@ -867,10 +867,10 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     if (sf.coarse) bytes += 8.0 * n + 1.0 * n;
     char name[56], pre_tag[8] = "";
     if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
-    snprintf(name, sizeof name, "slab_stream_f32<%d%s%s%s%s%s>", step, (U_in || sf.pre) ? "" : ",zero", sf.coarse ? ",prolong" : "",
-             sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
-    if (!sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps()) {
-        memcpy(name, "slab_tile  ", 11);
+    const bool as_tile = !sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps();
+    snprintf(name, sizeof name, "%s<%d%s%s%s%s%s>", as_tile ? "slab_tile_f32" : "slab_stream_f32", step, (U_in || sf.pre) ? "" : ",zero",
+             sf.coarse ? ",prolong" : "", sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
+    if (as_tile) {
         ProfScope ps(name, N, bytes);
         k::jacobi_tile_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, -1, (const float *)sf.coarse, sf.Nc, pt,
                            (float *)sf.Fc, sf.M, rt, sf.no_out, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr, sf.Fc ? &sf.fc_w : nullptr);

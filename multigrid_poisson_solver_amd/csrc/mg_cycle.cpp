@@ -160,6 +160,7 @@ struct mg_cycle_plan {
     int warm_runs = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int last_status = 0;
+    bool last_replayed = false;      // the last window was a hipGraph replay
     // ---- batched breadth-first schedule ------------------------------------------------------------------------------
     // The reference zeroes a level's U before every pre-smoothing except the restart case (src/MG_solver_CPU.cpp:252-257),
     // so a `-1` node reads nothing but its level's F.  When a cycle file comes back up to a level and descends from it
@@ -377,6 +378,34 @@ int trigger_smoothing(Exec &x, LevelNode *lv)
         before = lv->smoothingError;
     }
     return lv->step;
+}
+
+// The sweeps of the `1` node that will come back up to the level a `-1` node is about to leave (x.tok stands behind that
+// node's operands): the file's fixed step count, or -- per-node step counts, con_step = 0 -- the operand of the matching
+// `1` further down the stream (src/MG_solver_CPU.cpp:331-344).  -1: none (the file ends below, trigger mode).
+int matching_up_step(const Exec &x)
+{
+    const mg_cycle_plan *p = x.p;
+    if (p->con_step > 0) return p->con_step;
+    if (p->con_step != 0) return -1;
+    int depth = 1;
+    for (size_t tok = x.tok; tok < p->tokens.size();) {
+        const int node = (int)p->tokens[tok++];
+        if (node == 2) break;
+        if (node == -1) {
+            if (tok >= p->tokens.size()) break;
+            const int s = (int)p->tokens[tok++];
+            if (p->con_N == 0) ++tok;
+            if (s != 0) ++depth;          // (a 0-step `-1` node does nothing: :241-243)
+        } else if (node == 0) {
+            tok += 2;
+        } else if (node == 1) {
+            if (tok >= p->tokens.size()) break;
+            const int s = (int)p->tokens[tok++];
+            if (--depth == 0) return s;
+        }
+    }
+    return -1;
 }
 
 // materialise a pre-smoothed field that its `-1` node left to be recomputed (the rare consumer that is not the fused
@@ -645,7 +674,8 @@ void run_nodes(Exec &x)
                 if (!cycle.last()->U || !cycle.last()->F || !cycle.last()->D || !lv->U || !lv->D) { x.status = 14; break; }  // out of device memory
                 double *Fc = cycle.last()->F;
                 lv->pending_pre = 0;
-                if (!keep && p->con_step > 0 && recompute_available(next_N, lv->N, step, p->con_step)) {
+                const int up_step = keep ? -1 : matching_up_step(x);
+                if (up_step > 0 && recompute_available(next_N, lv->N, step, up_step)) {
                     // the `1` node of this level will redo these sweeps in its own pipeline: U is neither written now
                     // nor read then
                     smooth_restrict_no_out(lv->N, p->L, lv->U, lv->F, step, error_slot(p, rec), next_N, Fc);
@@ -1126,10 +1156,12 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     c.profile_window++;
     (void)hipEventRecord(p->ev0, s);
 
+    p->last_replayed = false;
     if (want_graph && p->graph_ready) {
         // the node program is static: replay it.  records/report keep their structure,
         // only the error values are refreshed at collect time.
         if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+        p->last_replayed = status == 0;
     } else {
         const bool mixed = (p->flags & MG_CYCLE_MIXED) != 0;
         const int outer = mixed ? p->refinements : 1;
@@ -1155,6 +1187,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
                     p->graph = g;
                     p->graph_ready = true;
                     if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+                    p->last_replayed = status == 0;
                 } else {
                     (void)hipGetLastError();
                     if (g) (void)hipGraphDestroy(g);
@@ -1195,6 +1228,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
                 p->graph = g;
                 p->graph_ready = true;
                 if (!MG_HIP(hipGraphLaunch(p->graph_exec, s))) status = 9;
+                p->last_replayed = status == 0;
                 if (dbg) fprintf(stderr, "[cycle] launched: status %d\n", status);
             } else {
                 (void)hipGetLastError();
@@ -1283,6 +1317,8 @@ int mg_cycle_collect(mg_cycle_plan *p, mg_cycle_result *out)
     out->n_records = (int)p->records.size();
     out->records = p->records.data();
     out->report = p->report.c_str();
+    out->graph_replayed = p->last_replayed ? 1 : 0;
+    out->schedule_launches = p->sched_ready ? (int)p->sched.size() : 0;
     return out->status;
 }
 

@@ -91,13 +91,16 @@ constexpr int MAX_S = 4;
 #endif
 
 // The recomputing fused `1` node (PRE sweeps from zero redone in flight + S post-smoothing sweeps, template parameter
-// PRE of k_jacobi_stream) exists for the pairs a fixed-step cycle file produces, PRE == S, as long as its pipeline of
-// L = PRE + S levels fits the register file at two waves per SIMD: V(1,1), V(2,2), V(3,3).  V(4,4) would be 8 levels
-// (two rows of history each: 64 more VGPRs than the 255 the 6-level kernel already uses) and stays store/re-read.
-// Builds with another prefetch depth have no such instantiation at all.  Everybody who decides to drop a level's U
-// (recompute_available, the slab schedule) asks this function, so a variant build can never drop a field it cannot
-// make again.
-constexpr bool recompute_instantiated(int pre, int steps) { return MG_PF == 2 && pre == steps && pre >= 1 && pre <= 3; }
+// PRE of k_jacobi_stream) exists for every pair whose pipeline of L = PRE + S levels is at most 6 deep: V(1,1), V(2,2),
+// V(3,3) of the fixed-step files and the unequal pairs a file with per-node step counts (con_step = 0) can ask for
+// (1+2, 2+1, 1+3, 3+1, 2+3, 3+2, 1+4, 4+1, 2+4, 4+2).  Six levels is what the F ring (8 rows in LDS, a row lives L + 2
+// steps) and two waves per SIMD hold; V(4,4) would be 8 levels and stays store/re-read.  Everybody who decides to drop a
+// level's U (recompute_available, the slab schedule) asks this function, so a variant build can never drop a field it
+// cannot make again.
+constexpr bool recompute_instantiated(int pre, int steps)
+{
+    return MG_PF == 2 && pre >= 1 && steps >= 1 && pre <= MAX_S && steps <= MAX_S && pre + steps <= 6;
+}
 
 enum InMode { IN_LOAD = 0, IN_ZERO = 1, IN_PROLONG = 2 };
 
@@ -1104,17 +1107,26 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
-        if constexpr (recompute_instantiated(S, S) && PF == 2) {
-            if (p.pre == S) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
-                // (rows in flight: with the F ring in LDS the registers for a deeper prefetch are there, MG_PF_UP)
-                constexpr int PFU = LdsRing<2, S>::value ? MG_PF_UP : PF;
-                if (nt) launch_k<S, 2, IN_PROLONG, false, PFU, true, S>(s, p, err_out);
-                else launch_k<S, 2, IN_PROLONG, false, PFU, false, S>(s, p, err_out);
-                return;
-            }
-        }
-        if (p.pre != 0) {  // (no instantiation for this S / PF: never read the absent input through the plain node)
-            fail(MG_ERR_UNSUPPORTED, "jacobi_stream: no recomputing `1` node for %d sweeps, prefetch depth %d", S, PF);
+        if (p.pre != 0) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)
+            bool done = false;
+            auto with_pre = [&](auto pre_tag) {
+                constexpr int PRE = decltype(pre_tag)::value;
+                if constexpr (recompute_instantiated(PRE, S) && PF == 2) {
+                    if (p.pre == PRE && !done) {
+                        // (rows in flight: with the F ring in LDS the registers for a deeper prefetch are there, MG_PF_UP)
+                        constexpr int PFU = LdsRing<2, PRE>::value ? MG_PF_UP : PF;
+                        if (nt) launch_k<S, 2, IN_PROLONG, false, PFU, true, PRE>(s, p, err_out);
+                        else launch_k<S, 2, IN_PROLONG, false, PFU, false, PRE>(s, p, err_out);
+                        done = true;
+                    }
+                }
+            };
+            with_pre(std::integral_constant<int, 1>{});
+            with_pre(std::integral_constant<int, 2>{});
+            with_pre(std::integral_constant<int, 3>{});
+            with_pre(std::integral_constant<int, 4>{});
+            // (no instantiation for this pair / prefetch depth: never read the absent input through the plain node)
+            if (!done) fail(MG_ERR_UNSUPPORTED, "jacobi_stream: no recomputing `1` node for %d + %d sweeps, prefetch depth %d", p.pre, S, PF);
             return;
         }
         if (nt) launch_k<S, 2, IN_PROLONG, false, PF, true>(s, p, err_out);
@@ -1149,7 +1161,7 @@ inline void run(hipStream_t s, int N, real_t dx2, real_t inv, const real_t *in, 
         return;
     }
     if (pre != 0 && !(recompute_instantiated(pre, steps) && coarse && !Fc)) {
-        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for 1+1, 2+2 and 3+3 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
+        fail(MG_ERR_ARG, "jacobi_stream: recomputed pre-smoothing exists for pre + steps <= 6 sweeps of the fused `1` node (pre=%d steps=%d)", pre, steps);
         return;
     }
     if (pre != 0 && D_out) {

@@ -78,6 +78,7 @@ def test_generated_vcycle_1024_vs_oracle(mg, oracle, tmp_path, smoother):
             for _ in range(3 if graph else 1):
                 got = plan.execute(fetch_U=True)
             check_against(got, want, zero_sign=fused)
+            assert got["graph_replayed"] == graph and got["schedule_launches"] == 0   # (a V-cycle has nothing to merge)
             plan.close()
     finally:
         mg.set_smoother("stream")
@@ -86,9 +87,9 @@ def test_generated_vcycle_1024_vs_oracle(mg, oracle, tmp_path, smoother):
 @pytest.mark.parametrize("steps", [1, 2, 4])
 def test_other_sweep_counts_through_the_cycle_driver(mg, oracle, tmp_path, steps):
     """V(1,1), V(2,2), V(4,4) and the W-cycle of the same sweep counts: the recomputing node pair (levels from
-    MG_RECOMPUTE_MIN_N on: 256 in this suite) is instantiated for 1+1, 2+2 and 3+3 sweeps, 4+4 falls back to
-    store/re-read (its pipeline of 8 levels does not fit the register file) -- all bit for bit like the oracle, eager and
-    replayed from a graph."""
+    MG_RECOMPUTE_MIN_N on: 256 in this suite) is instantiated for every pair of at most 6 sweeps together, 4+4 falls back
+    to store/re-read (its pipeline of 8 levels does not fit) -- all bit for bit like the oracle, eager and replayed from a
+    graph."""
     assert mg.lib().mg_recompute_pair_available(steps, steps) == (1 if steps <= 3 else 0)
     for kind, N in (("V", 1024), ("W", 512)):
         path = str(tmp_path / f"{kind}{steps}.txt")
@@ -100,6 +101,37 @@ def test_other_sweep_counts_through_the_cycle_driver(mg, oracle, tmp_path, steps
                 got = plan.execute(fetch_U=True)
             check_against(got, want, zero_sign=True)
             plan.close()
+
+
+@pytest.mark.parametrize("down,up", [(1, 2), (2, 1), (1, 3), (3, 1), (2, 3), (3, 2), (1, 4), (4, 1), (2, 4), (4, 2), (4, 3), (3, 4)])
+def test_unequal_sweep_counts_per_node(mg, oracle, tmp_path, down, up):
+    """Cycle files with per-node step counts (con_step = 0, src/MG_solver_CPU.cpp:171-189, :331-344): `down` sweeps before
+    every restriction, `up` after every prolongation.  The driver looks the matching `1` node's count up when it leaves a
+    level and drops that level's U whenever the recomputing pair exists for the two counts (down + up <= 6:
+    mg_recompute_pair_available; 4+3 and 3+4 stay store/re-read) -- V- and W-shaped files, bit for bit like the oracle."""
+    assert mg.lib().mg_recompute_pair_available(down, up) == (1 if down + up <= 6 else 0)
+    for kind, N in (("V", 1024), ("W", 512)):
+        sizes = []
+        n = N
+        while n >= 8:
+            sizes.append(n)
+            n //= 2
+        last = len(sizes) - 1
+
+        def visit(level):
+            if level == last:
+                return ["0", "0.0000001 1"]
+            body = ["-1", str(down)] + visit(level + 1) + ["1", str(up)]
+            return body * (2 if kind == "W" and level > 0 else 1)
+
+        path = str(tmp_path / f"{kind}_{down}_{up}.txt")
+        with open(path, "w") as f:
+            f.write(f"1.0 0.0 0.0\n0 1\n{N} 8\n" + "\n".join(visit(0)) + "\n2")
+        want = oracle.run_cycle_file(path)
+        plan = mg.CyclePlan(path, fused=True)
+        for _ in range(2):
+            check_against(plan.execute(fetch_U=True), want, zero_sign=True)
+        plan.close()
 
 
 def test_generated_wcycle_full_depth_vs_oracle(mg, oracle, tmp_path):
@@ -181,7 +213,11 @@ def test_wcycle_batched_schedule_back_to_back(mg, oracle, tmp_path, N, steps):
             check_against(plan.execute(fetch_U=True), want, zero_sign=True)
         for _ in range(4):
             plan.enqueue()
-        check_against(plan.collect(fetch_U=True), want, zero_sign=True)
+        got = plan.collect(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        # the result says how the window ran: as a batched schedule (2 launches per level above the coarse tail + the tail),
+        # and -- with MG_CYCLE_GRAPH -- as a replay of the captured graph
+        assert got["graph_replayed"] == graph and 0 < got["schedule_launches"] <= 2 * 8 + 1
         assert mg.lastExactSolverIterations() == oracle.gs_iterations()
         plan.close()
 

@@ -153,15 +153,17 @@ def test_weak_scaling_grid_sizes():
 
 
 def test_recompute_pair_and_closed_form_owner_predicates(m):
-    """Host-side predicates the kernels rely on (no device needed): the recomputing node pair exists for 1+1, 2+2 and 3+3
-    sweeps in the default build (mg_recompute_pair_available); and the closed form the register-tile kernel uses for the
+    """Host-side predicates the kernels rely on (no device needed): the recomputing node pair exists for every pair of at most
+    six sweeps together (1..4 each) in the default build (mg_recompute_pair_available); and the closed form the register-tile kernel uses for the
     owner cell of the fused prolongation, min(k*(Nc-1)/(N-1), Nc-2), reproduces the tables built from the reference's
     ceil() expressions for the level pairs of halving hierarchies (ProlongTable::closed_form verifies this entry by
     entry at run time; here the same comparison on the host for a spread of sizes, incl. an odd fine size where the
     kernel would read the tables)."""
     lib = m.load_library()
     assert [lib.mg_recompute_pair_available(s, s) for s in (1, 2, 3, 4)] == [1, 1, 1, 0]
-    assert lib.mg_recompute_pair_available(3, 2) == 0 and lib.mg_recompute_pair_available(0, 3) == 0
+    assert [[lib.mg_recompute_pair_available(a, b) for b in (1, 2, 3, 4)] for a in (1, 2, 3, 4)] == \
+        [[1, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1, 0], [1, 1, 0, 0]]   # pre + post <= 6
+    assert lib.mg_recompute_pair_available(0, 3) == 0 and lib.mg_recompute_pair_available(5, 1) == 0
     for Nc, N in [(64, 128), (128, 256), (512, 1024), (1024, 2048), (362, 724), (45, 90), (352, 704), (90, 181), (33, 64), (2048, 4096)]:
         k = np.arange(N, dtype=np.int64)
         want = np.minimum(k * (Nc - 1) // (N - 1), Nc - 2)

@@ -227,7 +227,8 @@ def test_bench_self_launches_its_ranks(mg):
     """`python3 bench.py --gpus 2` outside torchrun must start its two ranks itself (a child torch.distributed.run,
     before the parent touches the GPU) and relay rank 0's ONE JSON line: the shape of the command the driver uses
     for the scaling run.  Two RCCL ranks cannot share this box's one GPU, so the wire is the host-staged
-    rehearsal transport; the line must carry both legs (weak = `value`, strong = N 16384^2)."""
+    rehearsal transport; the line must carry every leg (weak = `value`, strong = N 16384^2, the headline grid 8192^2 cut
+    into slabs)."""
     import json
     import subprocess
     import sys
@@ -243,6 +244,9 @@ def test_bench_self_launches_its_ranks(mg):
     assert line["metric"] == "vcycle_mlups" and line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["N"] == 11520 and line["value"] > 0
     assert line["strong_scaling"]["N"] == 16384 and line["strong_scaling"]["value"] > 0
+    # BASELINE.json's metric reads "8192^2 fp64, 1/2/4/8 GPUs": the headline grid itself cut into slabs is in every line
+    assert line["strong_scaling_8192"]["N"] == 8192 and line["strong_scaling_8192"]["n_gpus"] == 2 and line["strong_scaling_8192"]["value"] > 0
+    assert line["strong_scaling_8192"]["mg_error"] == pytest.approx(0.000883, abs=2e-6)
     assert 0 < line["mg_error"] < 1e-3                                     # 11520 -> ... -> 11: another hierarchy, another error
     assert line["strong_scaling"]["mg_error"] == pytest.approx(0.000883, abs=2e-6)   # the V(3,3) result of the 2^k hierarchies
     # the line certifies its own wire: the communicator's rank count (not the environment's), where the transport came from,
