@@ -143,6 +143,9 @@ struct mg_cycle_plan {
     double *F_finest = nullptr;      // getSource(N_max), evaluated once at load (:153)
     double *F64 = nullptr, *U64 = nullptr;  // mixed mode: the fp64 source and the widened result
     int refinements = 1;             // mixed mode: fp32 cycles per window (fp64 residual + correction between them)
+    int refine_it = 0;               // ... and which of them is running
+    float *F32_res = nullptr;        // the fp32 source of the correction cycles (the rounded residual of the fp64 iterate): an array
+                                     // of its own, so that the rounded source of the first cycle never has to be made again
     bool F32_stale = false;          // the finest fp32 F holds a residual, not the rounded source
     double *refine_err_dev = nullptr;
     std::vector<double> refine_err;
@@ -734,8 +737,8 @@ void run_nodes(Exec &x)
                 if (step <= 0) { x.status = 15; break; }
                 const int rec = add_record(p, 1, fine->N, step);
                 // the node that ends the file on the finest level stores its result in fp64 straight away
-                // (single-cycle windows; a refinement adds the correction in a pass of its own)
-                const bool last_node = fine->N == p->N_max && p->refinements == 1 && k::stream_fusable(fine->N) &&
+                // (the first cycle of a window: a correction cycle's result is ADDED to the iterate, in a pass of its own)
+                const bool last_node = fine->N == p->N_max && p->refine_it == 0 && k::stream_fusable(fine->N) &&
                                        prolong_table(coarse->N, fine->N).fusable &&
                                        (x.tok >= p->tokens.size() || (int)p->tokens[x.tok] == 2);
                 const int pre = fine->pending_pre;  // > 0: the `-1` node of this level left U to be recomputed here
@@ -1201,12 +1204,15 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         for (int it = 0; it < outer && status == 0 && !p->sched_ready; ++it) {
         reset_levels(p);  // records/report: those of the last fp32 cycle
         c.active_pool = &p->pool;
+        p->refine_it = it;
         if (it > 0) {
-            // fp64 residual of the fp64 iterate -> fp32 source of the next correction cycle
+            // fp64 residual of the fp64 iterate -> fp32 source of the next correction cycle (in its own array when there
+            // is one: the finest level then simply points at it for this cycle)
             const double dx = p->L / (double)(p->N_max - 1);
-            k::refine_residual(s, p->N_max, 1.0 / (dx * dx), p->U64, p->F64, (float *)p->levels->first()->F,
-                               p->refine_err_dev + (it - 1));
-            p->F32_stale = true;
+            float *dst = p->F32_res ? p->F32_res : (float *)p->levels->first()->F;
+            k::refine_residual(s, p->N_max, 1.0 / (dx * dx), p->U64, p->F64, dst, p->refine_err_dev + (it - 1));
+            if (p->F32_res) p->levels->first()->F = (double *)p->F32_res;
+            else p->F32_stale = true;
         }
         Exec x{p, c};
         const bool capture_now = want_graph && p->warm_runs >= 1;  // run 0 warms pool + tables
@@ -1244,6 +1250,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
         }
         c.active_pool = nullptr;
         p->warm_runs++;
+        p->levels->first()->F = p->F_finest;   // (a correction cycle ran on the residual array)
         LevelNode *last = p->levels->last();
         p->final_U = last->U;
         p->final_N = last->N;
@@ -1350,6 +1357,7 @@ int mg_cycle_set_refinement(mg_cycle_plan *p, int cycles)
         p->refine_err_dev = (double *)p->pool.get(64 * sizeof(double));
         if (!p->refine_err_dev) return 1;
     }
+    if (cycles > 1 && !p->F32_res) p->F32_res = (float *)p->pool.get((size_t)p->N_max * p->N_max * sizeof(float));   // (nullptr: the source array is reused and re-made)
     p->refinements = cycles;
     return 0;
 }
@@ -1379,6 +1387,7 @@ void mg_cycle_destroy(mg_cycle_plan *p)
     drop_schedule(p);   // (the arrays the trace set aside go back to the pool)
     if (p->err_dev) p->pool.put(p->err_dev);
     if (p->refine_err_dev) p->pool.put(p->refine_err_dev);
+    if (p->F32_res) p->pool.put(p->F32_res);
     if (p->F64) p->pool.put(p->F64);
     if (p->U64) p->pool.put(p->U64);
     p->pool.trim();

@@ -180,6 +180,57 @@ __global__ __launch_bounds__(TB) void k_refine_residual(int N, double inv, const
     if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// The same for even N with 16 B per lane: a thread owns two adjacent columns and walks RR rows with a rolling window of
+// three row pairs in registers (every row of U is read once as aligned pairs; the two outer neighbours are single doubles,
+// L1 hits of the neighbouring lanes' pairs); non-temporal loads and stores: at N = 32768 the arrays are 4-8 GiB each and
+// every byte is touched once.  The expressions are k_refine_residual's (star_minus4's order: row+1, row-1, col+1, col-1).
+constexpr int RR = 8;
+typedef double dpair_t __attribute__((ext_vector_type(2)));
+typedef float fpair_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(TB) void k_refine_residual_pairs(int N, double inv, const double *__restrict__ U,
+                                                              const double *__restrict__ F, float *__restrict__ src,
+                                                              double *__restrict__ part)
+{
+    const int c2 = blockIdx.x * TB + threadIdx.x;   // column pair
+    const int c = 2 * c2;
+    const int r0 = blockIdx.y * RR;
+    double acc = 0.0;
+    if (c < N) {
+        const int cl = c > 0 ? c - 1 : 0, cr = c + 2 < N ? c + 2 : N - 1;
+        auto row_pair = [&](int r) {
+            r = r < 0 ? 0 : (r < N ? r : N - 1);
+            return __builtin_nontemporal_load(reinterpret_cast<const dpair_t *>(U + (size_t)r * N + c));
+        };
+        dpair_t up = row_pair(r0 - 1), mid = row_pair(r0);
+#pragma unroll
+        for (int k = 0; k < RR; ++k) {
+            const int r = r0 + k;
+            if (r >= N) break;
+            const dpair_t down = row_pair(r + 1);
+            const size_t p = (size_t)r * N + c;
+            const double left = U[(size_t)r * N + cl], right = U[(size_t)r * N + cr];
+            const dpair_t f = __builtin_nontemporal_load(reinterpret_cast<const dpair_t *>(F + p));
+            double v0 = 0.0, v1 = 0.0;
+            if (!rim(r, c, N)) {
+                v0 = inv * (down.x + up.x + mid.y + left - 4 * mid.x) - f.x;
+                if (((r + c) & 1) == 0) acc += fabs(v0);
+            }
+            if (!rim(r, c + 1, N)) {
+                v1 = inv * (down.y + up.y + right + mid.x - 4 * mid.y) - f.y;
+                if (((r + c + 1) & 1) == 0) acc += fabs(v1);
+            }
+            fpair_t o;
+            o.x = (float)(-v0);
+            o.y = (float)(-v1);
+            __builtin_nontemporal_store(o, reinterpret_cast<fpair_t *>(src + p));
+            up = mid;
+            mid = down;
+        }
+    }
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
 // the same on a row window (slab mode): rows [own_lo, own_hi) of arrays whose first row is `base`; the
 // halo rows own_lo - 1 and own_hi of U must be there; the norm is left as this slab's raw sum
 __global__ __launch_bounds__(TB) void k_refine_residual_rows(int N, double inv, const double *__restrict__ U,
@@ -212,6 +263,18 @@ __global__ __launch_bounds__(TB) void k_add_widened(double *__restrict__ U, cons
 {
     const size_t stride = (size_t)gridDim.x * TB;
     for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += stride) U[i] = U[i] + (double)e[i];
+}
+
+// ... two elements per lane (16 B of U), one shot, non-temporal: every byte of the 12 GiB is touched once
+__global__ __launch_bounds__(TB) void k_add_widened_pairs(double *__restrict__ U, const float *__restrict__ e, size_t n2)
+{
+    const size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n2) return;
+    dpair_t u = __builtin_nontemporal_load(reinterpret_cast<const dpair_t *>(U) + i);
+    const fpair_t d = __builtin_nontemporal_load(reinterpret_cast<const fpair_t *>(e) + i);
+    u.x = u.x + (double)d.x;
+    u.y = u.y + (double)d.y;
+    __builtin_nontemporal_store(u, reinterpret_cast<dpair_t *>(U) + i);
 }
 
 enum FinishMode { FIN_SMOOTH_ERR = 0, FIN_MEAN_NN = 1, FIN_RAW = 2 };
@@ -690,6 +753,14 @@ void convert_to_f64(hipStream_t s, double *dst, const float *src, size_t n)
 
 void refine_residual(hipStream_t s, int N, double inv, const double *U, const double *F, float *src, double *err_out)
 {
+    if (N % 2 == 0 && N >= 1024) {   // 16 B per lane, rolling row window (same expressions, same bits)
+        const dim3 g((N / 2 + TB - 1) / TB, (N + RR - 1) / RR);
+        const size_t np = (size_t)g.x * g.y;
+        double *part = partials(np);
+        hipLaunchKernelGGL(k_refine_residual_pairs, g, dim3(TB), 0, s, N, inv, U, F, src, part);
+        finish(s, part, np, FIN_SMOOTH_ERR, N, err_out);
+        return;
+    }
     const dim3 g = grid_rows(N, ROWS_PB);
     const size_t np = (size_t)g.x * g.y;
     double *part = partials(np);
@@ -712,6 +783,11 @@ void refine_residual_rows(hipStream_t s, int N, double inv, const double *U, con
 }
 void add_widened(hipStream_t s, double *U, const float *e, size_t n)
 {
+    if (n % 2 == 0 && n >= ((size_t)1 << 20) && ((uintptr_t)U % 16) == 0 && ((uintptr_t)e % 8) == 0) {
+        const size_t n2 = n / 2;
+        hipLaunchKernelGGL(k_add_widened_pairs, dim3((unsigned)((n2 + TB - 1) / TB)), dim3(TB), 0, s, U, e, n2);
+        return;
+    }
     hipLaunchKernelGGL(k_add_widened, dim3(grid_flat(n)), dim3(TB), 0, s, U, e, n);
 }
 
