@@ -308,10 +308,62 @@ struct WavesPerSimd {
 #ifndef MG_LDS_RING
 #define MG_LDS_RING 1
 #endif
+// PACKED fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two fp32 operations per lane and instruction, the
+// only way to the fp32 rate of the vector unit): the 4-columns-per-lane form of the fp32 kernels evaluates its column
+// pairs (0,1) and (2,3) with them.  Every element still sees the reference's operations in the reference's order (each
+// packed instruction rounds its two elements like the scalar one), so the numpy restatement still pins the bits.
+#ifndef MG_PACKED_F32
+#define MG_PACKED_F32 1
+#endif
+typedef float pk_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_t pk(float a, float b)
+{
+    pk_t r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+__device__ __forceinline__ pk_t pk_fma(pk_t a, pk_t b, pk_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pk_t pk_div_by_const(pk_t x, float c, float rc)   // div_by_const (mg_divconst.h) on two elements
+{
+    const pk_t cc = pk(c, c), rr = pk(rc, rc);
+    pk_t q = x * rr;
+    pk_t r = pk_fma(-q, cc, x);
+    q = pk_fma(r, rr, q);
+    r = pk_fma(-q, cc, x);
+    return pk_fma(r, rr, q);
+}
 template <int COLS, int PRE>
 struct LdsRing {
-    static constexpr bool value = MG_LDS_RING && PRE > 0 && COLS == 2;
+    // (fp32 fields with 4 columns -- 16 B -- per lane as well: the ring is what makes that form of the node fit two waves per SIMD)
+    static constexpr bool value = MG_LDS_RING && PRE > 0 && (COLS == 2 || (COLS == 4 && sizeof(real_t) == 4));
 };
+// a lane's COLS columns of one row as one LDS access, and the half of them the error norm counts in a row
+template <int COLS> struct RingVec { typedef real_t full; typedef real_t half; };
+template <> struct RingVec<2> { typedef real2_t full; typedef real_t half; };
+template <> struct RingVec<4> { typedef real4_t full; typedef real2_t half; };
+template <int COLS>
+__device__ __forceinline__ typename RingVec<COLS>::full ring_pack(const Row<COLS> &r)
+{
+    typename RingVec<COLS>::full t;
+    if constexpr (COLS == 1) t = r.v[0];
+    else {
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) t[j] = r.v[j];
+    }
+    return t;
+}
+template <int COLS>
+__device__ __forceinline__ Row<COLS> ring_unpack(const typename RingVec<COLS>::full &t)
+{
+    Row<COLS> r;
+    if constexpr (COLS == 1) r.v[0] = t;
+    else {
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) r.v[j] = t[j];
+    }
+    return r;
+}
 #ifndef MG_PF_UP
 #define MG_PF_UP 3    // rows of F (and coarse rows) in flight per lane in the LDS-ring form of the `1` node
 #endif
@@ -335,6 +387,7 @@ void k_jacobi_stream(const StreamParams p)
     constexpr int L = S + PRE;                         // levels of the pipeline
     constexpr bool LDSR = LdsRing<COLS, PRE>::value;   // F rows in LDS (dx2*F for the sweeps, one column of F for the norm)
     constexpr bool HALF = LDSR;                        // norm-only residual stage: one column per row
+    constexpr bool PACKED = MG_PACKED_F32 && COLS == 4 && sizeof(real_t) == 4;   // column pairs through packed fp32 instructions
 #ifndef MG_TB_DIRECT
 #define MG_TB_DIRECT 0
 #endif
@@ -343,8 +396,10 @@ void k_jacobi_stream(const StreamParams p)
     constexpr int NFR = LDSR ? 4 : NB;                 // F rows held in registers (LDSR: the rows in flight only)
     static_assert((LDSR ? L + 2 <= NB : PF + L + 2 <= NB) && PF < 4, "the F ring has NB slots, the U ring 4");
     static_assert(!LDSR || (IN == IN_PROLONG && !RESTRICT), "the LDS ring belongs to the recomputing `1` node");
-    __shared__ real2_t s_g[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];   // dx2*F, rows yin-L .. yin
-    __shared__ real_t s_f[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];    // F of the column the norm counts
+    typedef typename RingVec<COLS>::full ring_t;
+    typedef typename RingVec<COLS>::half ringh_t;
+    __shared__ ring_t s_g[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];    // dx2*F, rows yin-L .. yin
+    __shared__ ringh_t s_f[LDSR ? WAVES_PER_WG : 1][LDSR ? NB : 1][LDSR ? 64 : 1];   // F of the columns the norm counts
     constexpr int W = 64 * COLS;
     constexpr int H = Halo<L, RESTRICT, COLS>::value;
     constexpr int OW = W - 2 * H;  // columns a wave owns
@@ -596,12 +651,10 @@ void k_jacobi_stream(const StreamParams p)
     }
 
     if constexpr (LDSR) {  // (rows before the first arrival are read by pipeline levels nobody consumes: keep them finite)
-        real2_t z;
-        z.x = z.y = real_t(0.0);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            s_g[wave][k][lane] = z;
-            s_f[wave][k][lane] = real_t(0.0);
+            s_g[wave][k][lane] = ring_t(real_t(0.0));
+            s_f[wave][k][lane] = ringh_t(real_t(0.0));
         }
     }
 
@@ -736,11 +789,23 @@ void k_jacobi_stream(const StreamParams p)
                 if (own_i >= 0) {
                     const real_t own_yh = lane_value(tb_yh, t & 63), own_yl = lane_value(tb_yl, t & 63);
                     const real_t c_dx = p.c_dx, c_rcp = p.c_dx_rcp;
+                    if constexpr (PACKED) {
 #pragma unroll
-                    for (int j = 0; j < COLS; ++j) {
-                        const real_t num = hA[j] * own_yh + hB[j] * own_yl;
-                        const real_t pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
-                        row.v[j] = row.v[j] + pv;
+                        for (int j = 0; j < COLS; j += 2) {
+                            const pk_t yh2 = pk((float)own_yh, (float)own_yh), yl2 = pk((float)own_yl, (float)own_yl);
+                            const pk_t num = pk((float)hA[j], (float)hA[j + 1]) * yh2 + pk((float)hB[j], (float)hB[j + 1]) * yl2;
+                            const pk_t pv = pk_div_by_const(pk_div_by_const(num, (float)c_dx, (float)c_rcp), (float)c_dx, (float)c_rcp);
+                            const pk_t sum = pk((float)row.v[j], (float)row.v[j + 1]) + pv;
+                            row.v[j] = sum.x;
+                            row.v[j + 1] = sum.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < COLS; ++j) {
+                            const real_t num = hA[j] * own_yh + hB[j] * own_yl;
+                            const real_t pv = div_by_const(div_by_const(num, c_dx, c_rcp), c_dx, c_rcp);
+                            row.v[j] = row.v[j] + pv;
+                        }
                     }
                 }
             };
@@ -764,6 +829,43 @@ void k_jacobi_stream(const StreamParams p)
                 const real_t west0 = from_lane_below(c.v[COLS - 1]);
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> o;
+                if constexpr (PACKED) {
+                    // the same expressions on the column pairs (0,1) and (2,3): east of (0,1) is (1,2), west of (2,3) too
+                    const pk_t qA = pk((float)hi_bits_and(qc[0], inner), (float)hi_bits_and(qc[1], inner));
+                    const pk_t qB = pk((float)hi_bits_and(qc[2], inner), (float)hi_bits_and(qc[3], inner));
+                    const pk_t gA = pk((float)g.v[0], (float)g.v[1]), gB = pk((float)g.v[2], (float)g.v[3]);
+                    pk_t oA, oB;
+                    if ((IN == IN_ZERO || PRE > 0) && MG_ZERO_LEVEL1 && l == 1) {
+                        oA = pk_fma(qA, -gA, pk(0.0f, 0.0f));
+                        oB = pk_fma(qB, -gB, pk(0.0f, 0.0f));
+                    } else {
+                        const pk_t cA = pk((float)c.v[0], (float)c.v[1]), cB = pk((float)c.v[2], (float)c.v[3]);
+                        const pk_t mid = pk((float)c.v[1], (float)c.v[2]);
+                        const pk_t wA = pk((float)west0, (float)c.v[0]), eB = pk((float)c.v[3], (float)east_last);
+                        const pk_t m4 = pk(-4.0f, -4.0f);
+                        pk_t tA = pk((float)nw.v[0], (float)nw.v[1]) + pk((float)so.v[0], (float)so.v[1]);
+                        pk_t tB = pk((float)nw.v[2], (float)nw.v[3]) + pk((float)so.v[2], (float)so.v[3]);
+                        tA = tA + mid;   // + east
+                        tB = tB + eB;
+                        tA = tA + wA;    // + west
+                        tB = tB + mid;
+                        tA = pk_fma(m4, cA, tA) - gA;   // - 4U - dx2 F
+                        tB = pk_fma(m4, cB, tB) - gB;
+                        oA = pk_fma(qA, tA, cA);
+                        oB = pk_fma(qB, tB, cB);
+                    }
+                    o.v[0] = oA.x;
+                    o.v[1] = oA.y;
+                    o.v[2] = oB.x;
+                    o.v[3] = oB.y;
+                    older[l - 1] = c;
+                    newer[l - 1] = nw;
+                    nw = o;
+                    if constexpr (IN == IN_PROLONG && PRE > 0) {
+                        if (l == PRE) add_prolongation(nw);
+                    }
+                    continue;
+                }
                 if constexpr ((IN == IN_ZERO || PRE > 0) && MG_ZERO_LEVEL1) {
                     if (l == 1) {
                         // the first sweep from the zero field: every neighbour and the point itself are +0, so the sum,
@@ -807,19 +909,25 @@ void k_jacobi_stream(const StreamParams p)
                 // the F row of THIS step (issued PF steps ago) goes to the rings; level 1 reads it in the next step.
                 // Row yin has the parity of k + L + 1 (the march starts on an even row): an even row counts its even column
                 const Row<COLS> &fin = fr[k % NFR];
-                real2_t t;
-                t.x = dx2 * fin.v[0];
-                t.y = dx2 * fin.v[1];
-                s_g[wave][k % NB][lane] = t;
-                s_f[wave][k % NB][lane] = fin.v[(k + L + 1) & 1];
+                Row<COLS> gin;
+#pragma unroll
+                for (int j = 0; j < COLS; ++j) gin.v[j] = dx2 * fin.v[j];
+                s_g[wave][k % NB][lane] = ring_pack<COLS>(gin);
+                constexpr int par = (k + L + 1) & 1;
+                if constexpr (COLS == 2) {
+                    s_f[wave][k % NB][lane] = fin.v[par];
+                } else {
+                    ringh_t h;
+                    h.x = fin.v[par];
+                    h.y = fin.v[par + 2];
+                    s_f[wave][k % NB][lane] = h;
+                }
                 // ... and the rows of dx2*F the L levels of the NEXT step consume are requested now (level 1's is the row just
                 // written: the LDS operations of a wave execute in order), so their round trips lie under this step's tail
                 // and the next step's head instead of in front of every level
 #pragma unroll
                 for (int l = 1; l <= L; ++l) {
-                    const real2_t r = s_g[wave][(k + 1 - l + 2 * NB) % NB][lane];
-                    gq[l].v[0] = r.x;
-                    gq[l].v[1] = r.y;
+                    gq[l] = ring_unpack<COLS>(s_g[wave][(k + 1 - l + 2 * NB) % NB][lane]);
                 }
             }
 
@@ -861,14 +969,19 @@ void k_jacobi_stream(const StreamParams p)
                 const int cm = (mine_row && (unsigned)(y - p.norm_y0) < rows_norm) ? inner : 0;  // -1: the row counts
                 const Row<COLS> c = newer[L], so = older[L];
                 if constexpr (HALF) {
-                    // norm only: row y has the parity of k, its counted column is j = k & 1 (xl is even)
-                    constexpr int j = k & 1;
-                    const real_t fv = s_f[wave][(k - L - 1 + 2 * NB) % NB][lane];
-                    const real_t w = j == 0 ? from_lane_below(c.v[1]) : c.v[0];
-                    const real_t e = j == 0 ? c.v[1] : from_lane_above(c.v[0]);
-                    const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - fv;
-                    const int am = ((lane_owns && !col_edge[j]) ? -1 : 0) & cm;
-                    acc += fabs(bits_and((double)r, am));
+                    // norm only: row y has the parity of k, its counted columns are j = k & 1 (+ 2, + 4 ...: xl is even)
+                    const ringh_t fh = s_f[wave][(k - L - 1 + 2 * NB) % NB][lane];
+#pragma unroll
+                    for (int j = k & 1; j < COLS; j += 2) {
+                        real_t fv;
+                        if constexpr (COLS == 2) fv = fh;
+                        else fv = fh[j >> 1];
+                        const real_t w = j == 0 ? from_lane_below(c.v[COLS - 1]) : c.v[j > 0 ? j - 1 : 0];
+                        const real_t e = j == COLS - 1 ? from_lane_above(c.v[0]) : c.v[j < COLS - 1 ? j + 1 : 0];
+                        const real_t r = inv * minus4(nw.v[j] + so.v[j] + e + w, c.v[j]) - fv;
+                        const int am = ((lane_owns && !col_edge[j]) ? -1 : 0) & cm;
+                        acc += fabs(bits_and((double)r, am));
+                    }
                     older[L] = newer[L];
                     newer[L] = nw;
                     st_off += row_bytes;
@@ -1086,6 +1199,10 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         // fp32 fields, 16 B per lane: the same kernel with 4 columns per lane (8 B per lane leaves it bound by its
         // instruction stream at half the bytes per instruction of the fp64 build).  Not the recomputing `1` node: its
         // 6-level pipeline needs 267 VGPRs with 4 columns (one wave per SIMD: 270 us at N = 8192) and 144 with 2
+        // (Not the recomputing `1` node: measured at N = 8192 with its F rows in LDS (LdsRing<4, PRE>: 201 VGPRs, two waves per
+        // SIMD) the 4-column form takes 237 us with scalar and 233 us with packed arithmetic against 212 us of the 2-column
+        // form at four waves per SIMD -- its instruction stream carries ~155 scalar instructions per row step, SGPR spills
+        // included; profiles/r04_f32_packed_experiment.txt.  The instantiation is not built.)
         if (p.cols4 && !(prolong_in && p.pre)) {
             if (restrict_out) {
                 if (zero) launch_k<S, 4, IN_ZERO, true, PF>(s, p, err_out);
