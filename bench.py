@@ -132,7 +132,8 @@ def compulsory_bytes(kernel_family, N):
     S-sweep launch: U, F in, U out.  2 B/pt of table/halo overhead are not counted."""
     n = float(N) * N
     if "widen" in kernel_family:   # fp32 `1` node that stores its result in fp64: counted in fp64-equivalent units (x 0.5 later)
-        return 24.0 * n + 8.0 * (N // 2) ** 2 + 8.0 * n
+        # F, coarse U in (fp32), the result out in fp64 (twice an fp32 array); the pre-smoothed U in unless it is recomputed
+        return (8.0 if "pre" in kernel_family else 16.0) * n + 8.0 * (N // 2) ** 2 + 16.0 * n
     if "restrict" in kernel_family:   # noU: the smoothed field is not stored (its `1` node recomputes it)
         return (8.0 if "noU" in kernel_family else 16.0) * n + 8.0 * (N // 2) ** 2
     if "prolong" in kernel_family:    # pre3: the pre-smoothed field is recomputed (3 sweeps from zero), not read

@@ -367,6 +367,9 @@ __device__ __forceinline__ Row<COLS> ring_unpack(const typename RingVec<COLS>::f
 #ifndef MG_PF_UP
 #define MG_PF_UP 3    // rows of F (and coarse rows) in flight per lane in the LDS-ring form of the `1` node
 #endif
+#ifndef MG_PF_DOWN
+#define MG_PF_DOWN 3  // (3: 151 -> 147.5 us at 8192, same 131 VGPRs)  rows of F in flight per lane in the zero-start `-1` node
+#endif
 #ifndef MG_WPE_UP
 #define MG_WPE_UP 2   // (3 = 168 VGPRs: the allocator spills 15-27 dwords, and a spill reload drains the load queue: 580 us)   waves per SIMD the allocator is asked to make room for in the LDS-ring form of the `1` node
 #endif
@@ -571,7 +574,11 @@ void k_jacobi_stream(const StreamParams p)
 #pragma unroll
     for (int j = 0; j < COLS; ++j) ms[j] = col_edge[j] ? real_t(0.0) : (p.d_sign < 0 ? real_t(-1.0) : real_t(1.0));
 
-    const int y0e = HALF ? (y0 & ~1) : y0;                        // HALF: the march starts on an even row
+    // Lanes that hold column pairs start on an even column (xl is even), and the march starts on an even row (a chunk
+    // that begins on an odd row takes one step more): the parity of every row is then a compile-time property of its
+    // position in the loop body, and so is WHICH of a lane's columns the error norm counts in it ((row + col) even).
+    constexpr bool EVEN_START = COLS >= 2;
+    const int y0e = EVEN_START ? (y0 & ~1) : y0;
     const int y_first = y0e - (L + 1);                            // first input row
     const int T = (y1 - y0e) + 2 * (L + 1) + (RESTRICT ? 1 : 0);  // input rows consumed
     const int y_end = y_first + T;                                // one past the last input row
@@ -1002,8 +1009,13 @@ void k_jacobi_stream(const StreamParams p)
                         d.v[j] = r;  // (masked and signed where it is stored, below: most launches store no residual)
                     }
                     // (row+col) even interior points only, :610/:617; norms are accumulated in fp64 whatever the field type
-                    const int am = ((k & 1) ? nm_k1[j] : nm_k0[j]) & cm;
-                    acc += fabs(bits_and((double)r, am));
+                    if constexpr (EVEN_START) {
+                        // row y has the parity of k: only the columns of that parity can count (the others added +0.0)
+                        if ((j & 1) == (k & 1)) acc += fabs(bits_and((double)r, ((lane_owns && !col_edge[j]) ? -1 : 0) & cm));
+                    } else {
+                        const int am = ((k & 1) ? nm_k1[j] : nm_k0[j]) & cm;
+                        acc += fabs(bits_and((double)r, am));
+                    }
                 }
                 if constexpr (!RESTRICT) {
                     if (mine_row && lane_owns && p.D) {
@@ -1119,6 +1131,8 @@ void launch_k(hipStream_t s, StreamParams p, double *err_out)
         // is a multiple of the 8-step loop body (which has no exit inside)
         const int march = rows + 2 * (S + PRE + 1);
         rows += (8 - march % 8) % 8;
+    } else if (COLS >= 2) {
+        rows += rows & 1;   // chunks start on even rows (the kernel would otherwise march one row more per chunk)
     }
     chunks = (own + rows - 1) / rows;
     p.rows_per_chunk = rows;
@@ -1221,7 +1235,7 @@ void launch_variant(hipStream_t s, const StreamParams &p, double *err_out)
         if (zero) launch_k<S, 1, IN_ZERO, false, PF>(s, p, err_out);
         else launch_k<S, 1, IN_LOAD, false, PF>(s, p, err_out);
     } else if (restrict_out) {
-        if (zero) launch_k<S, 2, IN_ZERO, true, PF>(s, p, err_out);
+        if (zero) launch_k<S, 2, IN_ZERO, true, (PF == 2 && S <= 3 ? MG_PF_DOWN : PF)>(s, p, err_out);
         else launch_k<S, 2, IN_LOAD, true, PF>(s, p, err_out);
     } else if (prolong_in) {
         if (p.pre != 0) {  // the pre-smoothed U recomputed, not read (the caller checked recompute_available)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-window time of one cycle (no profiling events):  perf_window.py N [V|W] [eager|graph] [reps]
-Tuning knobs come from the environment (MG_CYCLE_FORK, MG_FORK_MAX_N, MG_FORK_STREAMS, GPU_MAX_HW_QUEUES, ...)."""
+Tuning knobs come from the environment (MG_CYCLE_BATCH, MG_BATCH_TAIL_N, MG_BATCH_RECOMPUTE_MIN_N, ...)."""
 import os
 import sys
 import tempfile
@@ -31,5 +31,5 @@ for _ in range(int(os.environ.get("TRIALS", "3"))):
     trials.append((time.perf_counter() - t0) / reps * 1e3)
     best = min(best, trials[-1])
 r = plan.collect()
-tags = " ".join(f"{k}={os.environ[k]}" for k in ("MG_CYCLE_FORK", "MG_FORK_MAX_N", "MG_FORK_STREAMS", "GPU_MAX_HW_QUEUES") if k in os.environ)
+tags = " ".join(f"{k}={os.environ[k]}" for k in ("MG_CYCLE_BATCH", "MG_BATCH_TAIL_N", "MG_BATCH_RECOMPUTE_MIN_N", "MG_RECOMPUTE_MIN_N") if k in os.environ)
 print(f"{kind}({N}) {mode:5s} {best:8.4f} ms per window (best of 3 x {reps}), status {r['status']}  {tags}  trials {' '.join(f'{t:.4f}' for t in trials)}", flush=True)
