@@ -396,8 +396,8 @@ void k_jacobi_stream(const StreamParams p)
 #endif
     constexpr bool TB_DIRECT = LDSR && MG_TB_DIRECT;   // table blocks loaded where they take over (no second set of registers)
     constexpr int NB = LDSR ? 8 : (PF + L + 2 <= 8 ? 8 : 16);  // slots of the F ring = row steps of the loop body
-    constexpr int NFR = LDSR ? 4 : NB;                 // F rows held in registers (LDSR: the rows in flight only)
-    static_assert((LDSR ? L + 2 <= NB : PF + L + 2 <= NB) && PF < 4, "the F ring has NB slots, the U ring 4");
+    constexpr int NFR = LDSR ? (PF < 4 ? 4 : 8) : NB;  // F rows held in registers (LDSR: the rows in flight only)
+    static_assert((LDSR ? L + 2 <= NB : PF + L + 2 <= NB) && PF < 8, "the F ring has NB slots, the U ring 4 or 8");
     static_assert(!LDSR || (IN == IN_PROLONG && !RESTRICT), "the LDS ring belongs to the recomputing `1` node");
     typedef typename RingVec<COLS>::full ring_t;
     typedef typename RingVec<COLS>::half ringh_t;
@@ -640,7 +640,7 @@ void k_jacobi_stream(const StreamParams p)
     for (int l = 0; l <= L; ++l)
 #pragma unroll
         for (int j = 0; j < COLS; ++j) older[l].v[j] = newer[l].v[j] = 0.0;
-    constexpr int NU = 4;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
+    constexpr int NU = PF < 4 ? 4 : 8;  // (a U row is consumed in the step it is due: PF < NU slots suffice)
     Row<COLS> fr[NFR], pu[NU];
     CoarseV<NCV> pc[NU];               // IN_PROLONG: coarse row (owner + 1) of the input row, 3 columns
     int q_own[NU];                // IN_PROLONG: owner coarse row of the input row
