@@ -222,6 +222,43 @@ def test_wcycle_batched_schedule_back_to_back(mg, oracle, tmp_path, N, steps):
         plan.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_irregular_cycle_trees_batched_vs_oracle(mg, oracle, tmp_path, seed):
+    """The dataflow trace on cycle files that are neither V nor W: every visit of a level descends 1, 2 or 3 times (drawn
+    per visit), so the levels carry batches of irregular sizes and sub-cycles of different lengths sit side by side --
+    the schedule's depth analysis has to order every node behind exactly what it reads.  Final U bit for bit, every
+    record, the report and the last solve's iteration count as the oracle's; eager and replayed from a graph."""
+    rng = np.random.default_rng(seed)
+    N = 512 if seed % 2 else 256
+    sizes = []
+    n = N
+    while n >= 8:
+        sizes.append(n)
+        n //= 2
+    last = len(sizes) - 1
+
+    def visit(level):
+        if level == last:
+            return ["0", "0.0000001 1"]
+        out = []
+        for _ in range(int(rng.integers(1, 4)) if level > 0 else 1):
+            out += ["-1"] + visit(level + 1) + ["1"]
+        return out
+
+    path = str(tmp_path / f"tree{seed}.txt")
+    with open(path, "w") as f:
+        f.write(f"1.0 0.0 0.0\n2 1\n{N} 8\n" + "\n".join(visit(0)) + "\n2")
+    want = oracle.run_cycle_file(path)
+    for graph in (False, True):
+        plan = mg.CyclePlan(path, fused=True, graph=graph)
+        for _ in range(3 if graph else 2):
+            got = plan.execute(fetch_U=True)
+            check_against(got, want, zero_sign=True)
+        assert got["graph_replayed"] == graph
+        assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+        plan.close()
+
+
 def test_wcycle_with_a_standalone_coarse_solve_is_interpreted(mg, oracle, tmp_path):
     """A W-cycle whose coarsest level lies above the LDS tail (512 -> 256 -> 128, two exact solves at N = 128 through the
     stand-alone solver and its device-side state): the dataflow trace gives up on the first such node (build_schedule:
