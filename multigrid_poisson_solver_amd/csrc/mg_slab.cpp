@@ -169,6 +169,9 @@ struct mg_slab_plan {
     int refinements = 1;         // mixed: fp32 cycles per window, joined by an fp64 residual and correction
     bool U64_current = false;    // U64 holds the result of the last window (refinement keeps it up to date)
     bool F32_stale = false;      // the finest fp32 F holds a residual, not the rounded source
+    std::vector<double *> F32_res;  // mixed, refinement: per local rank an fp32 window of its own for the residual source of the
+                                    // correction cycles (the rounded source of the first cycle then never has to be made again)
+    std::vector<double *> F32_src;  // ... and the finest level's own F arrays while a correction cycle points at F32_res
     double *refine_raw = nullptr;  // [refinements-1][n_local] raw residual norms of the intermediate iterates
     double *refine_all = nullptr;  // real mode: all-gather target
     std::vector<double> refine_err;
@@ -958,6 +961,14 @@ int mg_slab_enqueue(mg_slab_plan *p)
                 exchange_ghosts(p, 0, {GhostItem{&top, ARR_U, 1, &p->U64, sizeof(double)}});
                 exchange_join(p, 0);
             }
+            const bool own_array = it > 0 && p->F32_res.size() == p->local.size();
+            if (own_array) {  // the correction cycle's source lives in its own windows: the finest level points at them
+                p->F32_src.clear();
+                for (size_t i = 0; i < p->local.size(); ++i) {
+                    p->F32_src.push_back(top.loc[i].F);
+                    top.loc[i].F = p->F32_res[i];
+                }
+            }
             for (size_t i = 0; i < p->local.size(); ++i) {
                 const RowWindow w = window_of(top, p->local[i]);
                 if (it > 0) {
@@ -974,9 +985,14 @@ int mg_slab_enqueue(mg_slab_plan *p)
                 exchange_ghosts(p, 0, {GhostItem{&top, ARR_F, p->lp[0].needF}});
                 exchange_join(p, 0);
             }
-            p->F32_stale = it > 0;
+            p->F32_stale = it > 0 && !own_array;
         }
         run(p);
+        if (!p->F32_src.empty()) {  // back to the rounded source of the first cycle
+            Level &t0 = p->levels[0];
+            for (size_t i = 0; i < p->local.size(); ++i) t0.loc[i].F = p->F32_src[i];
+            p->F32_src.clear();
+        }
         if (p->mixed && outer > 1 && p->status == 0) {
             // fp64 correction on the owned rows: U64 = (double)e on the first cycle, U64 += (double)e afterwards
             Level &top = p->levels[0];  // (run() grows the level vector: the reference above is gone)
@@ -1123,6 +1139,21 @@ int mg_slab_set_refinement(mg_slab_plan *p, int cycles)
         if (p->real) p->refine_all = (double *)p->pool.get(64 * (size_t)p->nranks * sizeof(double));
         if (!p->refine_raw) return 1;
     }
+    if (cycles > 1 && p->F32_res.empty() && !p->levels.empty()) {
+        // windows of the finest level's geometry for the correction cycles' source (all or nothing: without them the
+        // source array is reused and re-rounded at the start of every window)
+        const Level &top = p->levels[0];
+        for (size_t i = 0; i < p->local.size(); ++i) {
+            const RowWindow w = window_of(top, p->local[i]);
+            double *b = (double *)p->pool.get((size_t)w.rows * top.N * sizeof(float));
+            if (!b) {
+                for (double *q : p->F32_res) p->pool.put(q);
+                p->F32_res.clear();
+                break;
+            }
+            p->F32_res.push_back(b);
+        }
+    }
     p->refinements = cycles;
     return 0;
 }
@@ -1150,6 +1181,7 @@ void mg_slab_destroy(mg_slab_plan *p)
     if (p->all_dev) p->pool.put(p->all_dev);
     for (double *b : p->U64) p->pool.put(b);
     for (double *b : p->F64) p->pool.put(b);
+    for (double *b : p->F32_res) p->pool.put(b);
     if (p->refine_raw) p->pool.put(p->refine_raw);
     if (p->refine_all) p->pool.put(p->refine_all);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
