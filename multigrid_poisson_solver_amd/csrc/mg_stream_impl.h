@@ -309,8 +309,8 @@ struct WavesPerSimd {
 #define MG_LDS_RING 1
 #endif
 // PACKED fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two fp32 operations per lane and instruction, the
-// only way to the fp32 rate of the vector unit): the 4-columns-per-lane form of the fp32 kernels evaluates its column
-// pairs (0,1) and (2,3) with them.  Every element still sees the reference's operations in the reference's order (each
+// only way to the fp32 rate of the vector unit): the fp32 kernels evaluate a lane's column pairs (0,1) [and (2,3)] with
+// them.  Every element still sees the reference's operations in the reference's order (each
 // packed instruction rounds its two elements like the scalar one), so the numpy restatement still pins the bits.
 #ifndef MG_PACKED_F32
 #define MG_PACKED_F32 1
@@ -390,7 +390,7 @@ void k_jacobi_stream(const StreamParams p)
     constexpr int L = S + PRE;                         // levels of the pipeline
     constexpr bool LDSR = LdsRing<COLS, PRE>::value;   // F rows in LDS (dx2*F for the sweeps, one column of F for the norm)
     constexpr bool HALF = LDSR;                        // norm-only residual stage: one column per row
-    constexpr bool PACKED = MG_PACKED_F32 && COLS == 4 && sizeof(real_t) == 4;   // column pairs through packed fp32 instructions
+    constexpr bool PACKED = MG_PACKED_F32 && (COLS == 2 || COLS == 4) && sizeof(real_t) == 4;   // column pairs through packed fp32 instructions
 #ifndef MG_TB_DIRECT
 #define MG_TB_DIRECT 0
 #endif
@@ -837,34 +837,29 @@ void k_jacobi_stream(const StreamParams p)
                 const real_t east_last = from_lane_above(c.v[0]);
                 Row<COLS> o;
                 if constexpr (PACKED) {
-                    // the same expressions on the column pairs (0,1) and (2,3): east of (0,1) is (1,2), west of (2,3) too
-                    const pk_t qA = pk((float)hi_bits_and(qc[0], inner), (float)hi_bits_and(qc[1], inner));
-                    const pk_t qB = pk((float)hi_bits_and(qc[2], inner), (float)hi_bits_and(qc[3], inner));
-                    const pk_t gA = pk((float)g.v[0], (float)g.v[1]), gB = pk((float)g.v[2], (float)g.v[3]);
-                    pk_t oA, oB;
-                    if ((IN == IN_ZERO || PRE > 0) && MG_ZERO_LEVEL1 && l == 1) {
-                        oA = pk_fma(qA, -gA, pk(0.0f, 0.0f));
-                        oB = pk_fma(qB, -gB, pk(0.0f, 0.0f));
-                    } else {
-                        const pk_t cA = pk((float)c.v[0], (float)c.v[1]), cB = pk((float)c.v[2], (float)c.v[3]);
-                        const pk_t mid = pk((float)c.v[1], (float)c.v[2]);
-                        const pk_t wA = pk((float)west0, (float)c.v[0]), eB = pk((float)c.v[3], (float)east_last);
-                        const pk_t m4 = pk(-4.0f, -4.0f);
-                        pk_t tA = pk((float)nw.v[0], (float)nw.v[1]) + pk((float)so.v[0], (float)so.v[1]);
-                        pk_t tB = pk((float)nw.v[2], (float)nw.v[3]) + pk((float)so.v[2], (float)so.v[3]);
-                        tA = tA + mid;   // + east
-                        tB = tB + eB;
-                        tA = tA + wA;    // + west
-                        tB = tB + mid;
-                        tA = pk_fma(m4, cA, tA) - gA;   // - 4U - dx2 F
-                        tB = pk_fma(m4, cB, tB) - gB;
-                        oA = pk_fma(qA, tA, cA);
-                        oB = pk_fma(qB, tB, cB);
+                    // the same expressions on the lane's column pairs (2P, 2P+1): the east neighbours of a pair are its second
+                    // column and the first of the next pair (or of the next lane), the west neighbours the mirror image
+#pragma unroll
+                    for (int P = 0; P < COLS / 2; ++P) {
+                        const int a = 2 * P, b = 2 * P + 1;
+                        const pk_t q2 = pk((float)hi_bits_and(qc[a], inner), (float)hi_bits_and(qc[b], inner));
+                        const pk_t g2 = pk((float)g.v[a], (float)g.v[b]);
+                        pk_t o2;
+                        if ((IN == IN_ZERO || PRE > 0) && MG_ZERO_LEVEL1 && l == 1) {
+                            o2 = pk_fma(q2, -g2, pk(0.0f, 0.0f));   // (the first sweep from the zero field, see below)
+                        } else {
+                            const pk_t c2 = pk((float)c.v[a], (float)c.v[b]);
+                            const pk_t e2 = pk((float)c.v[b], (float)(b == COLS - 1 ? east_last : c.v[b < COLS - 1 ? b + 1 : 0]));
+                            const pk_t w2 = pk((float)(a == 0 ? west0 : c.v[a > 0 ? a - 1 : 0]), (float)c.v[a]);
+                            pk_t t2 = pk((float)nw.v[a], (float)nw.v[b]) + pk((float)so.v[a], (float)so.v[b]);
+                            t2 = t2 + e2;
+                            t2 = t2 + w2;
+                            t2 = pk_fma(pk(-4.0f, -4.0f), c2, t2) - g2;   // - 4U - dx2 F
+                            o2 = pk_fma(q2, t2, c2);
+                        }
+                        o.v[a] = o2.x;
+                        o.v[b] = o2.y;
                     }
-                    o.v[0] = oA.x;
-                    o.v[1] = oA.y;
-                    o.v[2] = oB.x;
-                    o.v[3] = oB.y;
                     older[l - 1] = c;
                     newer[l - 1] = nw;
                     nw = o;
