@@ -18,5 +18,6 @@ python scripts/perf_levels.py 16384 > $O/vcycle_levels_16384.txt 2>&1
 python scripts/perf_slab.py 16384 8 > $O/slab8_16384.txt 2>&1
 python scripts/perf_slab.py 8192 8 > $O/slab8_8192.txt 2>&1
 python scripts/perf_slab.py 23040 8 > $O/slab8_23040.txt 2>&1
+python scripts/perf_slab.py 32768 8 > $O/slab8_32768.txt 2>&1
 scripts/profile.sh r04 > $O/profile_tail.txt 2>&1
 echo collected
