@@ -295,6 +295,9 @@ int  mg_slab_schedule(int N_max, int N_min, int nranks, int collapse_N, int step
  * at least MG_RECOMPUTE_MIN_N = 4096 points per side; MG_SLAB_RECOMPUTE=0 switches it off): such a level has no U
  * halo.  Returns the number of levels. */
 int  mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out);
+/* the same for a plan of `nranks` slabs: what decides is the size of a launch -- N * (N / nranks) >= MG_RECOMPUTE_MIN_N^2 / 2
+ * points -- so the smaller distributed levels of a many-rank plan store and re-read their U (and exchange its halo) */
+int  mg_slab_recompute_levels_ranks(int N_max, int N_min, int steps, int nranks, int *pre_out);
 /* host-only: 1 when this build holds the recomputing fused `1` node for `pre` pre-smoothing + `post` post-smoothing
  * sweeps (1+1, 2+2, 3+3 in the default build; none in a build with another prefetch depth): the node pair that
  * neither stores nor re-reads a level's pre-smoothed U (src/MG_solver_CPU.cpp:259 ... :416 of one level).  Other

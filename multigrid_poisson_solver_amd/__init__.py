@@ -87,7 +87,7 @@ ABI = {
     "mg_slab_partition": (_i, [_i, _i, _i, _i, _vp, _vp]), "mg_slab_ghost_rows": (_i, []),
     "mg_slab_set_refinement": (_i, [_vp, _i]), "mg_slab_refinement_errors": (_i, [_vp, _vp, _i]),
     "mg_slab_schedule": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mg_slab_recompute_levels": (_i, [_i, _i, _i, _vp]),
+    "mg_slab_recompute_levels": (_i, [_i, _i, _i, _vp]), "mg_slab_recompute_levels_ranks": (_i, [_i, _i, _i, _i, _vp]),
     "mg_recompute_pair_available": (_i, [_i, _i]),
     "mg_slab_load": (_vp, [C.c_char_p, _i, _i, _i]), "mg_slab_load_flags": (_vp, [C.c_char_p, _i, _i, _i, _i]), "mg_slab_execute": (_i, [_vp, C.POINTER(CycleResult)]),
     "mg_slab_enqueue": (_i, [_vp]), "mg_slab_collect": (_i, [_vp, C.POINTER(CycleResult)]),
@@ -578,7 +578,7 @@ def slab_schedule(N_max, N_min, nranks, collapse_N, steps, ca_mode=-1, ca_pct=-1
         lib_.mg_clear_error()
         raise MGError("mg_slab_schedule: a halo does not fit the neighbouring slab (raise collapse_N)")
     pre = np.zeros(nl, dtype=np.int32)
-    lib_.mg_slab_recompute_levels(N_max, N_min, steps, pre.ctypes.data)
+    lib_.mg_slab_recompute_levels_ranks(N_max, N_min, steps, nranks, pre.ctypes.data)
     out = []
     for l in range(nl):
         d = dict(N=int(lev[l, 0]), collapsed=bool(lev[l, 1]), halo=int(lev[l, 2]), needF=int(lev[l, 3]), xF=int(lev[l, 4]),

@@ -187,6 +187,9 @@ struct mg_cycle_plan {
     void *sched_items = nullptr;         // device: the instance tables of all groups
     bool sched_ready = false, sched_tried = false;
     int sched_max_batch = 0;
+    int sched_smoother = 0;              // the smoother setting the trace ran under (another one runs the file node by node)
+    double *sched_U = nullptr;           // where the schedule leaves the result
+    int sched_N = 0;
     int *gs_slots = nullptr;             // [2 * tails] exact-solver state per coarse-tail instance
     int last_tail = -1;                  // the tail whose state mg_lastExactSolverIterations() reports (last in file order)
 };
@@ -1010,8 +1013,9 @@ void build_schedule(mg_cycle_plan *p)
         return;
     }
     p->pool.park(false);   // (what the trace set aside stays set aside: those are the arrays of the schedule)
-    p->final_U = p->levels->last()->U;
-    p->final_N = p->levels->last()->N;
+    p->sched_U = p->final_U = p->levels->last()->U;
+    p->sched_N = p->final_N = p->levels->last()->N;
+    p->sched_smoother = (int)c.smoother;
     p->sched_ready = true;
     if (getenv("MG_CYCLE_DEBUG")) {
         fprintf(stderr, "[cycle] batched schedule: %zu nodes in %zu launches (largest batch %d), %.1f MiB of arrays\n", p->ops.size(), p->sched.size(),
@@ -1151,11 +1155,11 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
     if (!require_ready("mg_cycle_enqueue") || !p) return 1;
     Context &c = ctx();
     hipStream_t s = c.stream;
-    const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
-                            !uses_trigger(p) && !p->graph_failed;
     int status = 0;
     // first window: does the file's dataflow allow a batched schedule (independent visits of a level in one launch)?
     if (!p->sched_tried) build_schedule(p);
+    const bool want_graph = (p->flags & MG_CYCLE_GRAPH) && (p->flags & MG_CYCLE_FUSED) && !(p->flags & MG_CYCLE_MIXED) &&
+                            !uses_trigger(p) && !p->graph_failed && (!p->sched_ready || (int)c.smoother == p->sched_smoother);
     c.profile_window++;
     (void)hipEventRecord(p->ev0, s);
 
@@ -1173,8 +1177,12 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
             k::convert_to_f32(s, (float *)p->levels->first()->F, p->F64, n_top);
             p->F32_stale = false;
         }
-        if (p->sched_ready) {
+        // (mg_set_smoother after the trace: the schedule holds the trace's kernels, the interpreter follows the setting)
+        const bool use_sched = p->sched_ready && (int)c.smoother == p->sched_smoother;
+        if (use_sched) {
             // the schedule is static (arrays, records and report were fixed by the trace): its launches, nothing else
+            p->final_U = p->sched_U;
+            p->final_N = p->sched_N;
             const bool capture_now = want_graph && p->warm_runs >= 1;  // run 0 warms the tables and the norm arena
             bool capturing = false;
             if (capture_now) {
@@ -1201,7 +1209,7 @@ int mg_cycle_enqueue(mg_cycle_plan *p)
             }
             p->warm_runs++;
         }
-        for (int it = 0; it < outer && status == 0 && !p->sched_ready; ++it) {
+        for (int it = 0; it < outer && status == 0 && !use_sched; ++it) {
         reset_levels(p);  // records/report: those of the last fp32 cycle
         c.active_pool = &p->pool;
         p->refine_it = it;
@@ -1325,7 +1333,7 @@ int mg_cycle_collect(mg_cycle_plan *p, mg_cycle_result *out)
     out->records = p->records.data();
     out->report = p->report.c_str();
     out->graph_replayed = p->last_replayed ? 1 : 0;
-    out->schedule_launches = p->sched_ready ? (int)p->sched.size() : 0;
+    out->schedule_launches = (p->sched_ready && (int)c.smoother == p->sched_smoother) ? (int)p->sched.size() : 0;
     return out->status;
 }
 

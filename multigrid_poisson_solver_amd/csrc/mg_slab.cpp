@@ -572,6 +572,16 @@ int mg_slab_collect(mg_slab_plan *p, mg_cycle_result *out);
 //              per cent of a slab, in which case the next level's F halo is exchanged (xF) and the growth starts anew;
 //   xU[l]      rows of level l's U halo that have to travel because a `1` node reads them and the `-1` node did not
 //              update them.
+// Does level N of an nranks-slab plan run the recomputing node pair?  What decides is the size of a LAUNCH, not of the grid:
+// the pair pays from ~8 M points per launch on (one GPU: N = 4096 gains 35 us, N = 2048 loses 4; 8 slabs of the 8192 level --
+// 1024 x 8192 points each -- 90 against 101 us for the pair of launches, 8 slabs of the 4096 level 56 against 44:
+// `MG_RECOMPUTE_MIN_N=... scripts/perf_slab.py 16384 8`, window 4.12 -> 4.05 ms) -- i.e. N * rows per slab >= min_n^2 / 2.
+static bool slab_level_recomputes(int N, int nranks, int steps, int min_n)
+{
+    if (min_n <= 0 || !k::stream_recompute_supported(steps, steps) || N % 2 != 0) return false;
+    return (double)N * (double)(N / (nranks > 0 ? nranks : 1)) >= 0.5 * (double)min_n * (double)min_n;
+}
+
 // ca_mode: 0 = exchange every halo (one group per level, the round-1 schedule), 1 = recompute F halos (default),
 // 2 = recompute the U halos as well (no ghost exchange at all, only the collapse all-gather).
 // recompute_min: levels at least this large run the node pair that neither stores nor re-reads the pre-smoothed U
@@ -587,7 +597,7 @@ static bool slab_schedule(const std::vector<int> &sizes, const std::vector<Parti
     const int H2 = 2 * steps + 2;  // the same for the 2*steps levels of a recomputing `1` launch
     const size_t R = (size_t)nranks;
     std::vector<LevelPlan> lp(nl);
-    for (size_t l = 0; l < nd; ++l) lp[l].pre = (recompute_min > 0 && k::stream_recompute_supported(steps, steps) && sizes[l] >= recompute_min && sizes[l] % 2 == 0) ? steps : 0;
+    for (size_t l = 0; l < nd; ++l) lp[l].pre = slab_level_recomputes(sizes[l], nranks, steps, recompute_min) ? steps : 0;
     // F rows the launches of level `P` read: the `-1` launch around dext, the `1` launch around ext
     auto f_rows = [&](const LevelPlan &P, size_t r, int n) { return unite(grow(P.dext[r], H, n), grow(P.ext[r], P.pre ? H2 : H, n)); };
     // owned rows and the rows of the way up, finest level first
@@ -750,14 +760,15 @@ int mg_slab_ghost_rows(void) { return MIN_HALF; }
 
 // host-only: pre_out[l] = sweeps the `1` launch of level l recomputes from zero instead of reading the level's U
 // (0: the level stores and re-reads it), for the fp64 plan mg_slab_load would build
-int mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out)
+int mg_slab_recompute_levels_ranks(int N_max, int N_min, int steps, int nranks, int *pre_out)
 {
     int nl = 0;
     const int min_n = slab_recompute_min(false);
     for (int n = N_max; n >= N_min && n > 0; n /= 2, ++nl)
-        if (pre_out) pre_out[nl] = (min_n > 0 && k::stream_recompute_supported(steps, steps) && n >= min_n && n % 2 == 0) ? steps : 0;
+        if (pre_out) pre_out[nl] = slab_level_recomputes(n, nranks, steps, min_n) ? steps : 0;
     return nl;
 }
+int mg_slab_recompute_levels(int N_max, int N_min, int steps, int *pre_out) { return mg_slab_recompute_levels_ranks(N_max, N_min, steps, 1, pre_out); }
 
 // host-only: the schedule mg_slab_load derives for a hierarchy (`steps` sweeps per node; ca_mode / ca_pct < 0: the
 // defaults resp. env MG_SLAB_CA / MG_SLAB_CA_PCT).  level_out[l*6 + ..] = {N, collapsed, halo, needF, xF, xU};

@@ -222,6 +222,31 @@ def test_wcycle_batched_schedule_back_to_back(mg, oracle, tmp_path, N, steps):
         plan.close()
 
 
+def test_batched_plan_follows_a_later_smoother_setting(mg, oracle, tmp_path):
+    """A plan whose first window built a batched schedule holds the kernels of the smoother setting it was traced under;
+    mg_set_smoother afterwards makes the same plan run node by node with the other kernels, and back: every window the
+    oracle's, and the result says which way it ran."""
+    path = str(tmp_path / "W512.txt")
+    mg.write_wcycle_file(path, 512, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path)
+    plan = mg.CyclePlan(path, fused=True)
+    try:
+        got = plan.execute(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        assert got["schedule_launches"] > 0
+        mg.set_smoother("simple")
+        got = plan.execute(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        assert got["schedule_launches"] == 0
+        mg.set_smoother("stream")
+        got = plan.execute(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        assert got["schedule_launches"] > 0
+    finally:
+        mg.set_smoother("stream")
+        plan.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_irregular_cycle_trees_batched_vs_oracle(mg, oracle, tmp_path, seed):
     """The dataflow trace on cycle files that are neither V nor W: every visit of a level descends 1, 2 or 3 times (drawn

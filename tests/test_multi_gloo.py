@@ -52,13 +52,14 @@ def test_partition_properties():
     assert G >= 6
     # the bench configurations WITH THE PRODUCT'S THRESHOLDS (this process runs with the test suite's lower ones, see
     # conftest.py: a child process): the halos of the schedule fit, nothing but the last level's U halo travels, and
-    # the levels from 4096 on recompute their pre-smoothed field (such a level has no U halo at all)
+    # the levels whose slabs are large enough recompute their pre-smoothed field (such a level has no U halo at all)
     code = """
 import multigrid_poisson_solver_amd as mg
 for N, R in [(16384, 8), (23040, 8), (11520, 2), (16384, 4), (16384, 2)]:
     sched = [d for d in mg.slab_schedule(N, 8, R, 1024, 3) if not d["collapsed"]]
     assert all(d["xF"] == 0 for d in sched) and [d["xU"] > 0 for d in sched] == [False] * (len(sched) - 1) + [True], (N, R)
-    assert [d["pre"] for d in sched] == [3 if d["N"] >= 4096 else 0 for d in sched], (N, R)
+    # (the recomputing pair where a LAUNCH has at least 4096^2 / 2 points: N * rows per slab)
+    assert [d["pre"] for d in sched] == [3 if d["N"] * (d["N"] // R) >= 4096 * 4096 // 2 else 0 for d in sched], (N, R)
     assert all(d["xU"] == 0 for d in sched if d["pre"])
     for d in sched:
         rows = min(hi - lo for lo, hi in d["own"])
