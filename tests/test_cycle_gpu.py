@@ -222,6 +222,28 @@ def test_wcycle_batched_schedule_back_to_back(mg, oracle, tmp_path, N, steps):
         plan.close()
 
 
+def test_wcycle_16384_batched_vs_oracle(mg, oracle, tmp_path):
+    """The W-cycle one size above BASELINE config 3 (N = 16384^2: batches of up to 256 instances, 19 launches for 5118
+    nodes) against the oracle's own run: the final U through the 128-bit checksum, every record."""
+    import _synth
+    N = 16384
+    path = str(tmp_path / "W16384.txt")
+    mg.write_wcycle_file(path, N, 8, 3, 1e-7)
+    want = oracle.run_cycle_file(path, want_report=False)
+    plan = mg.CyclePlan(path, fused=True, report=False)
+    got = plan.execute()
+    s = (C.c_uint64 * 2)()
+    mg.lib().mg_checksum(got["U_ptr"], N * N, s)
+    assert got["status"] == 0 and want["status"] == 0 and 0 < got["schedule_launches"] <= 2 * 11 + 1
+    assert (int(s[0]), int(s[1])) == tuple(_synth.checksum(want["U"])), "W-cycle at 16384: final U differs from the oracle's"
+    assert len(got["records"]) == len(want["records"])
+    for g, w in zip(got["records"], want["records"]):
+        assert tuple(g[:3]) == tuple(w[:3]) and g[3] == pytest.approx(w[3], rel=1e-12, abs=1e-300)
+    assert got["mg_error"] == pytest.approx(want["mg_error"], rel=1e-10)
+    plan.close()
+    mg.lib().mg_pool_trim()
+
+
 def test_batched_plan_follows_a_later_smoother_setting(mg, oracle, tmp_path):
     """A plan whose first window built a batched schedule holds the kernels of the smoother setting it was traced under;
     mg_set_smoother afterwards makes the same plan run node by node with the other kernels, and back: every window the
