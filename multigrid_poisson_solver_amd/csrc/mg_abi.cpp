@@ -867,9 +867,9 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     if (sf.coarse) bytes += 8.0 * n + 1.0 * n;
     char name[56], pre_tag[8] = "";
     if (sf.pre) snprintf(pre_tag, sizeof pre_tag, ",pre%d", sf.pre);
-    const bool as_tile = !sf.pre && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps();
-    snprintf(name, sizeof name, "%s<%d%s%s%s%s%s>", as_tile ? "slab_tile_f32" : "slab_stream_f32", step, (U_in || sf.pre) ? "" : ",zero",
-             sf.coarse ? ",prolong" : "", sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
+    const bool as_tile = !sf.pre && !sf.out_wide && c.smoother == SMOOTHER_STREAM && k::tile_wanted_slab(N) && step <= k::tile_max_steps();
+    snprintf(name, sizeof name, "%s<%d%s%s%s%s%s%s>", as_tile ? "slab_tile_f32" : "slab_stream_f32", step, (U_in || sf.pre) ? "" : ",zero",
+             sf.coarse ? ",prolong" : "", sf.out_wide ? ",widen" : "", sf.Fc ? ",res,restrict" : "", sf.no_out ? ",noU" : "", pre_tag);
     if (as_tile) {
         ProfScope ps(name, N, bytes);
         k::jacobi_tile_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, -1, (const float *)sf.coarse, sf.Nc, pt,
@@ -879,7 +879,7 @@ void slab_smooth_f32(int N, double L, const float *U_in, float *U_out, const flo
     ProfScope ps(name, N, bytes);
     k::jacobi_stream_f32(c.stream, N, (float)dx2, (float)(1.0 / dx2), U_in, F, U_out, step, raw_norm_out, (const float *)sf.coarse,
                          sf.Nc, pt, (float *)sf.Fc, sf.M, rt, &sf.fine_w, sf.coarse ? &sf.coarse_w : nullptr,
-                         sf.Fc ? &sf.fc_w : nullptr, nullptr, nullptr, -1, sf.pre, sf.no_out);
+                         sf.Fc ? &sf.fc_w : nullptr, sf.out_wide, nullptr, -1, sf.pre, sf.no_out);
 }
 }  // namespace mg
 

@@ -179,6 +179,7 @@ struct SlabFusion {
     RowWindow fine_w, coarse_w, fc_w;
     int pre = 0;          // `1` launch: the pre-smoothed field is recomputed (pre sweeps from zero), U_in is not read
     bool no_out = false;  // `-1` launch: the smoothed field is not stored
+    double *out_wide = nullptr;  // fp32 fields: the result goes to this fp64 window (same geometry, exact widening) instead of U_out
 };
 void slab_smooth(int N, double L, const double *U_in, double *U_out, const double *F, int step, double *raw_norm_out,
                  const SlabFusion &sf);

@@ -168,6 +168,8 @@ struct mg_slab_plan {
     std::vector<double *> F64;   // mixed: per local rank, the fp64 source rows of the finest window
     int refinements = 1;         // mixed: fp32 cycles per window, joined by an fp64 residual and correction
     bool U64_current = false;    // U64 holds the result of the last window (refinement keeps it up to date)
+    int refine_it = 0;           // mixed, refinement: which cycle of the window is running
+    bool top_widened = false;    // ... and its last node stored the owned rows of the result in U64 itself
     bool F32_stale = false;      // the finest fp32 F holds a residual, not the rounded source
     std::vector<double *> F32_res;  // mixed, refinement: per local rank an fp32 window of its own for the residual source of the
                                     // correction cycles (the rounded source of the first cycle then never has to be made again)
@@ -539,6 +541,13 @@ void run(mg_slab_plan *p)
                     sf.coarse = coarse.loc[i].U;
                     sf.coarse_w = coarse.collapsed ? RowWindow{0, coarse.N, 0, coarse.N} : window_of(coarse, r);
                     sf.pre = p->lp[hier].pre;
+                    // the node that ends the first cycle of a refinement window on the finest level stores its rows of the
+                    // fp64 iterate itself (exact widening in the store: no conversion pass; as mg_cycle.cpp does on one GPU)
+                    if (p->mixed && p->refinements > 1 && p->refine_it == 0 && p->levels.size() == 1 && i < p->U64.size() &&
+                        (tok >= p->tokens.size() || (int)p->tokens[tok] == 2)) {
+                        sf.out_wide = p->U64[i];
+                        p->top_widened = true;
+                    }
                     if (p->mixed)
                         slab_smooth_f32(fine.N, p->L, sf.pre ? nullptr : (const float *)fine.loc[i].U, (float *)fine.loc[i].D,
                                         (const float *)fine.loc[i].F, step, raw_slot(p, (size_t)rec, i), sf);
@@ -998,6 +1007,8 @@ int mg_slab_enqueue(mg_slab_plan *p)
             }
             p->F32_stale = it > 0 && !own_array;
         }
+        p->refine_it = it;
+        p->top_widened = false;
         run(p);
         if (!p->F32_src.empty()) {  // back to the rounded source of the first cycle
             Level &t0 = p->levels[0];
@@ -1012,8 +1023,11 @@ int mg_slab_enqueue(mg_slab_plan *p)
                 const size_t n = (size_t)(w.own_hi - w.own_lo) * top.N;
                 double *u64 = row_ptr(p->U64[i], w, top.N, w.own_lo);
                 const float *e = (const float *)row_at(p, top.loc[i].U, w, top.N, w.own_lo);
-                if (it == 0) k::convert_to_f64(c.stream, u64, e, n);
-                else k::add_widened(c.stream, u64, e, n);
+                if (it == 0) {
+                    if (!p->top_widened) k::convert_to_f64(c.stream, u64, e, n);
+                } else {
+                    k::add_widened(c.stream, u64, e, n);
+                }
             }
             p->U64_current = true;
         }
