@@ -9,6 +9,8 @@
 // segment of a row.  The temporally blocked smoother lives in mg_stream.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mg_gs_wave.h"
 #include "mg_exp_table.h"
 #include "mg_internal.h"
@@ -110,6 +112,48 @@ __global__ __launch_bounds__(TB) void k_jacobi_pair(int N, double dx2, const dou
         }
     }
     __builtin_nontemporal_store(o, reinterpret_cast<double2_k *>(out + p));
+}
+
+// The same with PR rows per thread and a rolling window of three row pairs in registers: every row of `in` is read once as
+// the centre of its own row and stays in registers as the neighbour of the rows above and below (the one-row-per-block form
+// reads it three times, twice through L2), F is read once with a non-temporal load.  Same expressions, same bits.
+#ifndef MG_PAIR_ROWS
+#define MG_PAIR_ROWS 4
+#endif
+constexpr int PR = MG_PAIR_ROWS;
+__global__ __launch_bounds__(TB) void k_jacobi_pair_rows(int N, double dx2, const double *__restrict__ in,
+                                                         const double *__restrict__ F, double *__restrict__ out)
+{
+    const int c = 2 * (blockIdx.x * TB + threadIdx.x);
+    const int r0 = blockIdx.y * PR;
+    if (c >= N) return;
+    auto row_pair = [&](int r) {
+        r = r < 0 ? 0 : (r < N ? r : N - 1);   // (rows beyond the grid: clamped, never used -- rows 0 and N-1 keep their value)
+        return *reinterpret_cast<const double2_k *>(in + (size_t)r * N + c);
+    };
+    double2_k dn = row_pair(r0 - 1), ctr = row_pair(r0);
+#pragma unroll
+    for (int k = 0; k < PR; ++k) {
+        const int r = r0 + k;
+        if (r >= N) break;
+        const double2_k up = row_pair(r + 1);
+        const size_t p = (size_t)r * N + c;
+        double2_k o = ctr;
+        if (r > 0 && r < N - 1) {
+            const double2_k f = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(F + p));
+            if (c > 0) {
+                const double w = in[p - 1];
+                o.x = ctr.x + 0.25 * (up.x + dn.x + ctr.y + w - 4 * ctr.x - dx2 * f.x);
+            }
+            if (c + 1 < N - 1) {
+                const double e = in[p + 2];
+                o.y = ctr.y + 0.25 * (up.y + dn.y + e + ctr.x - 4 * ctr.y - dx2 * f.y);
+            }
+        }
+        __builtin_nontemporal_store(o, reinterpret_cast<double2_k *>(out + p));
+        dn = ctr;
+        ctr = up;
+    }
 }
 
 // ---------------------------------------------------------------- residual
@@ -694,6 +738,13 @@ void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const dou
 {
     const dim3 g = grid_rows(N, ROWS_PB);
     if (in && N % 2 == 0 && N >= 512) {
+        // (measured, scripts/perf_pair.py: N = 8192 321 -> 301 us = 0.63 -> 0.67 of the HBM peak, 16384 1215 -> 1130 us = 0.71; at 4096,
+        // where the arrays sit in the caches, the one-row form is faster: 62 against 73 us; 8 rows per thread lose at 8192: 358 us)
+        static const int pair_rows_min = [] { const char *e = getenv("MG_PAIR_ROWS_MIN_N"); return e ? atoi(e) : 8192; }();
+        if (N >= pair_rows_min) {
+            hipLaunchKernelGGL(k_jacobi_pair_rows, dim3((N / 2 + TB - 1) / TB, (N + PR - 1) / PR), dim3(TB), 0, s, N, dx2, in, F, out);
+            return;
+        }
         hipLaunchKernelGGL(k_jacobi_pair, dim3((N / 2 + TB - 1) / TB, N), dim3(TB), 0, s, N, dx2, in, F, out);
         return;
     }

@@ -431,6 +431,29 @@ def test_fullsize_smoothing_and_residual_checksums(mg, golden_fullsize, smoother
     mg.lib().mg_pool_trim()
 
 
+@pytest.mark.parametrize("N", [8192, 16384])
+def test_fullsize_single_sweeps_reach_the_reference_checksum(mg, golden_fullsize, N):
+    """north_star's yardstick kernel -- ONE Jacobi sweep per launch on a large grid (from N = 8192 on the multi-row form
+    of the pair kernel: four rows per thread, rolling row window in registers) -- pinned to the REFERENCE: three single
+    sweeps must give the checksum of the reference's doSmoothing(3) on the same hash-generated inputs, and one single
+    sweep the bits of the streaming kernel at S = 1."""
+    U, F, A, B = mg.DeviceGrid.uniform(N, 11), mg.DeviceGrid.uniform(N, 22), mg.DeviceGrid(N), mg.DeviceGrid(N)
+    mg.smooth_pp(N, 1.0, U, A, F, 1)
+    first = A.checksum()
+    mg.smooth_pp(N, 1.0, A, B, F, 1)
+    mg.smooth_pp(N, 1.0, B, A, F, 1)
+    assert list(A.checksum()) == golden_fullsize[f"smooth3_N{N}"]["checksum"]
+    mg.set_smoother("stream_only")
+    try:
+        mg.smooth_pp(N, 1.0, U, B, F, 1)
+    finally:
+        mg.set_smoother("stream")
+    assert B.checksum() == first
+    for g in (U, F, A, B):
+        g.free()
+    mg.lib().mg_pool_trim()
+
+
 def ulp_distance(a, b):
     """distance in units in the last place between two fp64 arrays of the same sign pattern"""
     ia, ib = a.view(np.int64), b.view(np.int64)
