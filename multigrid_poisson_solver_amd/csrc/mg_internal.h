@@ -77,9 +77,10 @@ public:
     void put(void *p);
     void trim();
     size_t bytes_held() const { return held_; }
-    // Reuse of a returned block normally relies on stream order (the next user enqueues behind the last one).  While
-    // a plan runs independent sub-cycles on several streams that no longer holds: with park(true) returned blocks are
-    // set aside instead of becoming available, until release_parked() -- called where all streams have been joined.
+    // Reuse of a returned block relies on stream order (the next user enqueues behind the last one).  While a cycle plan
+    // traces its node program for a batched schedule (mg_cycle.cpp: build_schedule) every visit of a level must keep
+    // arrays of its own: with park(true) returned blocks are set aside instead of becoming available, until
+    // release_parked() -- called when the schedule is dropped.
     void park(bool on) { park_ = on; }
     void release_parked();
 private:
