@@ -1,5 +1,7 @@
 """W(3,3)-cycle at a large size as a batched schedule against the oracle's own run: checksum of the final U, every record.\n   python scripts/check_w_large.py [N]   (N = 16384: 19 launches, ~4.2 ms; the oracle ~10 s on 16 threads)"""
 import os, sys, time, ctypes as C
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -222,6 +222,24 @@ def test_wcycle_batched_schedule_back_to_back(mg, oracle, tmp_path, N, steps):
         plan.close()
 
 
+@pytest.mark.parametrize("N,n_min,steps,batched", [(704, 8, 3, True), (1152, 9, 3, True), (1448, 8, 2, False), (360, 5, 1, False)])
+def test_wcycle_on_hierarchies_that_are_not_powers_of_two(mg, oracle, tmp_path, N, n_min, steps, batched):
+    """W-cycles down 704 -> 11, 1152 -> 9 (every level above the coarsest even: batched schedules with the register-tile
+    kernel on levels such as 44, 36 and 72 and coarse tails from 22 and 18 with an 11 x 11 / 9 x 9 solve) and down
+    1448 -> 11, 360 -> 5 (an odd level in mid-hierarchy -- 181, 45 -- is not a fused node: the trace gives up, the file
+    runs node by node): final U bit for bit, every record, the last solve's iteration count."""
+    path = str(tmp_path / f"W{N}.txt")
+    mg.write_wcycle_file(path, N, n_min, steps, 1e-7)
+    want = oracle.run_cycle_file(path)
+    plan = mg.CyclePlan(path, fused=True)
+    for _ in range(2):
+        got = plan.execute(fetch_U=True)
+        check_against(got, want, zero_sign=True)
+        assert (got["schedule_launches"] > 0) == batched
+        assert mg.lastExactSolverIterations() == oracle.gs_iterations()
+    plan.close()
+
+
 def test_wcycle_16384_batched_vs_oracle(mg, oracle, tmp_path):
     """The W-cycle one size above BASELINE config 3 (N = 16384^2: batches of up to 256 instances, 19 launches for 5118
     nodes) against the oracle's own run: the final U through the 128-bit checksum, every record."""
