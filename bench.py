@@ -75,7 +75,10 @@ def vcycle_algorithmic_bytes(sizes, nu1, nu2):
 RECOMPUTE_MIN_N = int(os.environ.get("MG_RECOMPUTE_MIN_N", "4096"))  # the library's default (mg_abi.cpp: recompute_available)
 
 
-def vcycle_compulsory_bytes(sizes, recompute=True, visits=None):
+BATCH_RECOMPUTE_MIN_N = int(os.environ.get("MG_RECOMPUTE_MIN_N", os.environ.get("MG_BATCH_RECOMPUTE_MIN_N", "1024")))  # batched schedules (mg_cycle.cpp: build_schedule)
+
+
+def vcycle_compulsory_bytes(sizes, recompute=True, visits=None, min_n=None):
     """HBM bytes one V-cycle of the FUSED driver cannot avoid: per level one `-1` launch (F in, U out, coarse F
     out: 16 n + 8 m) and one `1` launch (U, F, coarse U in, U out: 24 n + 8 m); from N = 4096 on the pair neither
     writes nor re-reads the pre-smoothed U (the `1` node recomputes it): 8 n + 8 m and 16 n + 8 m.  The coarse tail
@@ -85,7 +88,7 @@ def vcycle_compulsory_bytes(sizes, recompute=True, visits=None):
         if a <= 64:
             break
         # (visits: W-cycle, every visit of a level pair moves its bytes again)
-        total += (visits[l] if visits else 1) * ((24.0 if recompute and a >= RECOMPUTE_MIN_N else 40.0) * a * a + 16.0 * b * b)
+        total += (visits[l] if visits else 1) * ((24.0 if recompute and a >= (min_n or RECOMPUTE_MIN_N) else 40.0) * a * a + 16.0 * b * b)
     return total
 
 
@@ -446,7 +449,8 @@ def main():
     }
     out.update(pre_legs)
     if algo_bytes:
-        cb = vcycle_compulsory_bytes(sizes, visits=visits) * elem * refine
+        # (a W-cycle runs as a batched schedule, whose levels use the recomputing pair from N = 1024 on)
+        cb = vcycle_compulsory_bytes(sizes, visits=visits, min_n=BATCH_RECOMPUTE_MIN_N if args.cycle == "W" and not args.mixed else None) * elem * refine
         if refine > 1:   # per joint: fp64 iterate + fp64 source read, fp32 source written; fp32 correction read, fp64 iterate read + written
             cb += (refine - 1) * (8 + 8 + 4 + 4 + 8 + 8) * float(N) * N
         algo_bytes *= refine
