@@ -226,33 +226,36 @@ __global__ __launch_bounds__(TB) void k_refine_residual(int N, double inv, const
 
 // The same for even N with 16 B per lane: a thread owns two adjacent columns and walks RR rows with a rolling window of
 // three row pairs in registers (every row of U is read once as aligned pairs; the two outer neighbours are single doubles,
-// L1 hits of the neighbouring lanes' pairs); non-temporal loads and stores: at N = 32768 the arrays are 4-8 GiB each and
-// every byte is touched once.  The expressions are k_refine_residual's (star_minus4's order: row+1, row-1, col+1, col-1).
-constexpr int RR = 8;
+// L1 hits of the neighbouring lanes' pairs); F and the result through non-temporal accesses: at N = 32768 the arrays are
+// 4-8 GiB each and every byte of them is touched once.  The expressions are k_refine_residual's (star_minus4's order: row+1, row-1, col+1, col-1).
+constexpr int RR = 4;   // (as k_jacobi_pair_rows: 8 rows per thread lose)
 typedef double dpair_t __attribute__((ext_vector_type(2)));
 typedef float fpair_t __attribute__((ext_vector_type(2)));
+// (base / own_lo / own_hi: the arrays' first row and the rows to form -- the whole grid, or the window of a row slab, whose
+// halo rows own_lo - 1 and own_hi of U are there)
 __global__ __launch_bounds__(TB) void k_refine_residual_pairs(int N, double inv, const double *__restrict__ U,
                                                               const double *__restrict__ F, float *__restrict__ src,
-                                                              double *__restrict__ part)
+                                                              double *__restrict__ part, int base, int own_lo, int own_hi)
 {
     const int c2 = blockIdx.x * TB + threadIdx.x;   // column pair
     const int c = 2 * c2;
-    const int r0 = blockIdx.y * RR;
+    const int r0 = own_lo + blockIdx.y * RR;
     double acc = 0.0;
     if (c < N) {
         const int cl = c > 0 ? c - 1 : 0, cr = c + 2 < N ? c + 2 : N - 1;
+        const int lo = own_lo > 0 ? own_lo - 1 : 0, hi = own_hi < N ? own_hi : N - 1;   // rows of U that exist for this launch
         auto row_pair = [&](int r) {
-            r = r < 0 ? 0 : (r < N ? r : N - 1);
-            return __builtin_nontemporal_load(reinterpret_cast<const dpair_t *>(U + (size_t)r * N + c));
+            r = r < lo ? lo : (r < hi ? r : hi);
+            return *reinterpret_cast<const dpair_t *>(U + (size_t)(r - base) * N + c);   // (plain: the block's halo rows are its neighbours' rows)
         };
         dpair_t up = row_pair(r0 - 1), mid = row_pair(r0);
 #pragma unroll
         for (int k = 0; k < RR; ++k) {
             const int r = r0 + k;
-            if (r >= N) break;
+            if (r >= own_hi) break;
             const dpair_t down = row_pair(r + 1);
-            const size_t p = (size_t)r * N + c;
-            const double left = U[(size_t)r * N + cl], right = U[(size_t)r * N + cr];
+            const size_t p = (size_t)(r - base) * N + c;
+            const double left = U[(size_t)(r - base) * N + cl], right = U[(size_t)(r - base) * N + cr];
             const dpair_t f = __builtin_nontemporal_load(reinterpret_cast<const dpair_t *>(F + p));
             double v0 = 0.0, v1 = 0.0;
             if (!rim(r, c, N)) {
@@ -808,7 +811,7 @@ void refine_residual(hipStream_t s, int N, double inv, const double *U, const do
         const dim3 g((N / 2 + TB - 1) / TB, (N + RR - 1) / RR);
         const size_t np = (size_t)g.x * g.y;
         double *part = partials(np);
-        hipLaunchKernelGGL(k_refine_residual_pairs, g, dim3(TB), 0, s, N, inv, U, F, src, part);
+        hipLaunchKernelGGL(k_refine_residual_pairs, g, dim3(TB), 0, s, N, inv, U, F, src, part, 0, 0, N);
         finish(s, part, np, FIN_SMOOTH_ERR, N, err_out);
         return;
     }
@@ -824,6 +827,14 @@ void refine_residual_rows(hipStream_t s, int N, double inv, const double *U, con
     const int own = w.own_hi - w.own_lo;
     if (own <= 0) {
         (void)hipMemsetAsync(out_raw, 0, sizeof(double), s);
+        return;
+    }
+    if (N % 2 == 0 && N >= 1024) {   // 16 B per lane, rolling row window (same expressions, same bits)
+        const dim3 g((N / 2 + TB - 1) / TB, (own + RR - 1) / RR);
+        const size_t np = (size_t)g.x * g.y;
+        double *part = partials(np);
+        hipLaunchKernelGGL(k_refine_residual_pairs, g, dim3(TB), 0, s, N, inv, U, F, src, part, w.base, w.own_lo, w.own_hi);
+        finish(s, part, np, FIN_RAW, N, out_raw);
         return;
     }
     const dim3 g((N + TB - 1) / TB, (own + ROWS_PB - 1) / ROWS_PB);
