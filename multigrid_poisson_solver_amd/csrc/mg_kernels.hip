@@ -11,6 +11,7 @@
 
 #include <cstdlib>
 
+#include "mg_divconst.h"
 #include "mg_gs_wave.h"
 #include "mg_exp_table.h"
 #include "mg_internal.h"
@@ -172,6 +173,40 @@ __global__ __launch_bounds__(TB) void k_residual(int N, double inv, const double
         double v = 0.0;
         if (!rim(r, c, N)) v = inv * star_minus4(U, p, N) - F[p];
         D[p] = sign < 0 ? -v : v;
+    }
+}
+
+// getResidual on large even grids: 16 B per lane, PR rows per thread with a rolling window of three row pairs (every row of U
+// read once), F and D through non-temporal accesses -- the shape of k_jacobi_pair_rows.  Same expression (star_minus4's order).
+__global__ __launch_bounds__(TB) void k_residual_pairs(int N, double inv, const double *__restrict__ U,
+                                                       const double *__restrict__ F, double *__restrict__ D, int sign)
+{
+    const int c = 2 * (blockIdx.x * TB + threadIdx.x);
+    const int r0 = blockIdx.y * PR;
+    if (c >= N) return;
+    const int cl = c > 0 ? c - 1 : 0, cr = c + 2 < N ? c + 2 : N - 1;
+    auto row_pair = [&](int r) {
+        r = r < 0 ? 0 : (r < N ? r : N - 1);
+        return *reinterpret_cast<const double2_k *>(U + (size_t)r * N + c);
+    };
+    double2_k up = row_pair(r0 - 1), mid = row_pair(r0);
+#pragma unroll
+    for (int k = 0; k < PR; ++k) {
+        const int r = r0 + k;
+        if (r >= N) break;
+        const double2_k down = row_pair(r + 1);
+        const size_t p = (size_t)r * N + c;
+        double2_k v = {0.0, 0.0};
+        if (r > 0 && r < N - 1) {
+            const double left = U[(size_t)r * N + cl], right = U[(size_t)r * N + cr];
+            const double2_k f = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(F + p));
+            if (c > 0) v.x = inv * (down.x + up.x + mid.y + left - 4 * mid.x) - f.x;
+            if (c + 1 < N - 1) v.y = inv * (down.y + up.y + right + mid.x - 4 * mid.y) - f.y;
+        }
+        if (sign < 0) v = -v;
+        __builtin_nontemporal_store(v, reinterpret_cast<double2_k *>(D + p));
+        up = mid;
+        mid = down;
     }
 }
 
@@ -400,6 +435,40 @@ __global__ __launch_bounds__(TB) void k_restrict(int N, const T *__restrict__ Uf
 // src/MG_solver_CPU.cpp:688-700 turned into a gather over fine points: the owning
 // coarse cell and the four 1-D weight factors come from host tables that replay the
 // reference's ceil() ranges and last-row/column rules (:697-718).
+// doProlongation on large even fine grids whose every point has an owner cell (ProlongTable::fusable): two adjacent fine
+// columns (16 B) per lane, the result through a non-temporal store, `.../c_dx/c_dx` (:700) through the correctly rounded
+// division by a constant of mg_divconst.h -- the same bits as the IEEE division of k_prolong below, which stays the form the
+// small grids (and with them the operator tests against the oracle) run; the reference's own checksums pin this one at
+// 8192 ... 32768 (tests/test_parity_gpu.py).
+template <bool ADD>
+__global__ __launch_bounds__(TB) void k_prolong_pairs(int N, const double *__restrict__ Uc, int M, const double *__restrict__ Uf_in,
+                                                      double *__restrict__ Uf_out, const int *__restrict__ orow,
+                                                      const int *__restrict__ ocol, const double *__restrict__ row_hi,
+                                                      const double *__restrict__ row_lo, const double *__restrict__ col_hi,
+                                                      const double *__restrict__ col_lo, double c_dx, double c_rcp)
+{
+    const int l = 2 * (blockIdx.x * TB + threadIdx.x);
+    const int kf = blockIdx.y;
+    if (l >= M) return;
+    const int i = orow[kf];
+    const double yh = row_hi[kf], yl = row_lo[kf];
+    const size_t q = (size_t)kf * M + l;
+    const int j0 = ocol[l], j1 = ocol[l + 1];
+    const double2_k xh = *reinterpret_cast<const double2_k *>(col_hi + l), xl = *reinterpret_cast<const double2_k *>(col_lo + l);
+    const double *cu = Uc + (size_t)i * N, *cd = cu + N;
+    const double a1 = cu[j0], a2 = cu[j0 + 1], a3 = cd[j0], a4 = cd[j0 + 1];
+    const double b1 = cu[j1], b2 = cu[j1 + 1], b3 = cd[j1], b4 = cd[j1 + 1];
+    double2_k v;
+    v.x = div_by_const(div_by_const((a1 * xh.x + a2 * xl.x) * yh + (a3 * xh.x + a4 * xl.x) * yl, c_dx, c_rcp), c_dx, c_rcp);
+    v.y = div_by_const(div_by_const((b1 * xh.y + b2 * xl.y) * yh + (b3 * xh.y + b4 * xl.y) * yl, c_dx, c_rcp), c_dx, c_rcp);
+    if (ADD) {   // doGridAddition :569: U1 = U1 + U2
+        const double2_k u = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(Uf_in + q));
+        v.x = u.x + v.x;
+        v.y = u.y + v.y;
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<double2_k *>(Uf_out + q));
+}
+
 template <bool ADD, typename T>
 __global__ __launch_bounds__(TB) void k_prolong(int N, const T *__restrict__ Uc, int M, const T *__restrict__ Uf_in,
                                                 T *__restrict__ Uf_out, const int *__restrict__ orow,
@@ -431,6 +500,25 @@ __global__ __launch_bounds__(TB) void k_add(size_t n, double *__restrict__ a, co
 __global__ __launch_bounds__(TB) void k_negate(size_t n, double *__restrict__ a)
 {
     for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) a[i] = -a[i];
+}
+// the same on arrays far larger than the caches: two elements (16 B) per lane, one shot, non-temporal accesses
+__global__ __launch_bounds__(TB) void k_add_pairs(size_t n2, double *__restrict__ a, const double *__restrict__ b)
+{
+    const size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n2) return;
+    double2_k x = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(a) + i);
+    const double2_k y = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(b) + i);
+    x.x = x.x + y.x;
+    x.y = x.y + y.y;
+    __builtin_nontemporal_store(x, reinterpret_cast<double2_k *>(a) + i);
+}
+__global__ __launch_bounds__(TB) void k_negate_pairs(size_t n2, double *__restrict__ a)
+{
+    const size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n2) return;
+    double2_k x = __builtin_nontemporal_load(reinterpret_cast<const double2_k *>(a) + i);
+    x = -x;
+    __builtin_nontemporal_store(x, reinterpret_cast<double2_k *>(a) + i);
 }
 
 // fp64 <-> fp32 (mixed-precision mode): round to nearest / exact widening
@@ -696,6 +784,12 @@ __global__ __launch_bounds__(1024) void k_gs_check(const double *__restrict__ pa
 }
 
 inline dim3 grid_rows(int N, int rows_per_block) { return dim3((N + TB - 1) / TB, (N + rows_per_block - 1) / rows_per_block); }
+// operator-by-operator kernels: from this grid size on (arrays far larger than the caches) the 16-byte non-temporal forms
+inline int big_grid_min()
+{
+    static const int v = [] { const char *e = getenv("MG_BIG_GRID_MIN_N"); return e ? atoi(e) : 4096; }();
+    return v;
+}
 inline int grid_flat(size_t n)
 {
     size_t b = (n + TB - 1) / TB;
@@ -757,6 +851,10 @@ void jacobi_simple(hipStream_t s, int N, double dx2, const double *in, const dou
 
 void residual(hipStream_t s, int N, double inv, const double *U, const double *F, double *D, int sign)
 {
+    if (N % 2 == 0 && N >= big_grid_min()) {
+        hipLaunchKernelGGL(k_residual_pairs, dim3((N / 2 + TB - 1) / TB, (N + PR - 1) / PR), dim3(TB), 0, s, N, inv, U, F, D, sign);
+        return;
+    }
     hipLaunchKernelGGL(k_residual, grid_rows(N, ROWS_PB), dim3(TB), 0, s, N, inv, U, F, D, sign);
 }
 
@@ -780,6 +878,17 @@ void restrict_gather_f32(hipStream_t s, int N, const float *Uf, int M, float *Uc
 
 void prolong(hipStream_t s, int N, const double *Uc, int M, const double *Uf_in, double *Uf_out, const ProlongTable &t)
 {
+    if (M % 2 == 0 && M >= big_grid_min() && t.fusable) {
+        const dim3 g2((M / 2 + TB - 1) / TB, M);
+        const double rc = 1.0 / t.c_dx;   // IEEE division on the host: correctly rounded
+        if (Uf_in)
+            hipLaunchKernelGGL((k_prolong_pairs<true>), g2, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col, t.row_hi, t.row_lo,
+                               t.col_hi, t.col_lo, t.c_dx, rc);
+        else
+            hipLaunchKernelGGL((k_prolong_pairs<false>), g2, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col, t.row_hi, t.row_lo,
+                               t.col_hi, t.col_lo, t.c_dx, rc);
+        return;
+    }
     const dim3 g((M + TB - 1) / TB, M);
     if (Uf_in)
         hipLaunchKernelGGL((k_prolong<true, double>), g, dim3(TB), 0, s, N, Uc, M, Uf_in, Uf_out, t.owner_row, t.owner_col,
@@ -855,10 +964,18 @@ void add_widened(hipStream_t s, double *U, const float *e, size_t n)
 
 void add(hipStream_t s, size_t n, double *a, const double *b)
 {
+    if (n % 2 == 0 && n >= (size_t)big_grid_min() * big_grid_min() && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0) {
+        hipLaunchKernelGGL(k_add_pairs, dim3((unsigned)((n / 2 + TB - 1) / TB)), dim3(TB), 0, s, n / 2, a, b);
+        return;
+    }
     hipLaunchKernelGGL(k_add, dim3(grid_flat(n)), dim3(TB), 0, s, n, a, b);
 }
 void negate(hipStream_t s, size_t n, double *a)
 {
+    if (n % 2 == 0 && n >= (size_t)big_grid_min() * big_grid_min() && ((uintptr_t)a % 16) == 0) {
+        hipLaunchKernelGGL(k_negate_pairs, dim3((unsigned)((n / 2 + TB - 1) / TB)), dim3(TB), 0, s, n / 2, a);
+        return;
+    }
     hipLaunchKernelGGL(k_negate, dim3(grid_flat(n)), dim3(TB), 0, s, n, a);
 }
 

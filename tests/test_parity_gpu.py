@@ -530,6 +530,24 @@ def test_fullsize_transfer_checksums(mg, golden_fullsize, N):
     mg.lib().mg_pool_trim()
 
 
+def test_large_grid_forms_of_the_elementwise_operators(mg):
+    """From N = 4096 on the operator-by-operator kernels run their 16-byte non-temporal forms (k_residual_pairs, k_add_pairs,
+    k_negate_pairs, k_prolong_pairs; the residual and the prolongation are pinned by the reference's checksums in the tests
+    above): negation and addition against numpy on the same arrays, bit for bit."""
+    N = 4096
+    U, F, D, E = mg.DeviceGrid.uniform(N, 11), mg.DeviceGrid.uniform(N, 22), mg.DeviceGrid(N), mg.DeviceGrid(N)
+    mg.getResidual(N, 1.0, U, F, D)
+    d = D.to_host()
+    mg.negate(N, D)
+    assert_bits(D.to_host(), -d, "negate at 4096")
+    u, f = U.to_host(), F.to_host()
+    mg.doGridAddition(N, U, F)
+    assert_bits(U.to_host(), u + f, "doGridAddition at 4096")
+    for g in (U, F, D, E):
+        g.free()
+    mg.lib().mg_pool_trim()
+
+
 @pytest.mark.parametrize("N", [8192])
 def test_fullsize_properties(mg, smoother, N):
     """Size-independent properties at the headline size."""
